@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/sec through the fused demosaic + 10-slider develop kernel (BASELINE.json).
+
+Workload (configs[2] of BASELINE.json, the configuration the metric is quoted on; per GPU it is
+also config 4's share): a batch of 256 distinct synthetic 24 MP RGGB frames (6016 x 4016 u16,
+uniform 12-bit, seed 0x52415745) resident in HBM, one randomised slider stack per frame drawn from
+the UI ranges, wb = (2, 1, 1.5), non-identity colour matrix, RGBA-f32 surface written to a ring of
+output buffers, fused 3x256 histogram accumulated in u64.  One "step" = one pass over the batch:
+256 fused launches + the histogram fold (+ one RCCL all-reduce of 768 x i64 when N > 1).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` counts output pixels of all ranks over the max-over-ranks
+wall time of exactly K steps, inputs already resident in HBM.  `roofline` is the dominant kernel
+(rd_develop_quads) against the 8 TB/s HBM3E peak with the algorithmic 18 B/px of BASELINE.md section 2;
+its launch duration is measured here with HIP events on the launch stream.  `cpu_baseline` is the
+oracle (oracle/develop_ref.c, a port -- the reference has no CPU path) on the host cores, rank 0,
+N = 1 only, reported-only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0x52415745
+WB = (2.0, 1.0, 1.5, 1.0)
+CM = (1.6, -0.4, -0.2, -0.3, 1.5, -0.2, 0.0, -0.5, 1.5)
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+BYTES_PER_PX = {"f32": 18, "f16": 10, "u8": 6}   # 2 B CFA read + surface write
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=6016)
+    ap.add_argument("--height", type=int, default=4016)
+    ap.add_argument("--format", choices=["f32", "f16", "u8"], default="f32")
+    ap.add_argument("--ring", type=int, default=8, help="output buffers cycled through")
+    ap.add_argument("--row-bands", type=int, default=1)
+    ap.add_argument("--no-hist", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(width, height, budget_s):
+    """The oracle, row-parallel over every host core, on whole frames of the same workload."""
+    import numpy as np
+    from oracle import ref_c
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng([SEED, 0])
+    cfa = rng.integers(0, 4096, (height, width), dtype=np.uint16)
+    from raweditor_amd import EditParams, FIELDS
+    p = EditParams.random(np.random.default_rng([SEED, 1]))
+    u = ref_c.make_uniforms({f: getattr(p, f) for f in FIELDS}, WB, CM)
+    out = np.empty((height, width, 4), np.float32)
+    import ctypes as C
+    L = ref_c.lib()
+    args = (cfa.ctypes.data_as(C.POINTER(C.c_uint16)), width, height, C.byref(u), width, height, 0,
+            out.ctypes.data_as(C.POINTER(C.c_float)), cores)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        L.ref_render_f32_mt(*args)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or frames >= 16:
+            break
+    mp = frames * width * height / 1e6
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(mp / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} x {width}x{height} frame(s), randomised stack, f32 surface, "
+                      f"{el:.1f} s on {cores} threads ({model})"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import raweditor_amd as ra
+    from raweditor_amd.batch import allreduce_histogram
+
+    W, H, F = args.width, args.height, args.frames
+    fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8}[args.format]
+    bpp_out = ra.BYTES_PER_PIXEL[fmt]
+    with_hist = not args.no_hist
+
+    # ---- synthetic batch, generated on the device, keyed by (seed, global frame index) ------------
+    cfas, params = [], []
+    for f in range(F):
+        gidx = rank + f * world                           # frame i -> rank i mod N
+        g = torch.Generator(device=dev)
+        g.manual_seed(SEED + gidx)
+        cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
+        params.append(ra.EditParams.random(np.random.default_rng([SEED, gidx])))
+    ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
+    hist = torch.zeros(768, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    be = ra.BatchExporter(local_rank, W, H, fmt, with_hist)
+    frames = be.make_frames([c.data_ptr() for c in cfas], [ring[i % len(ring)].data_ptr() for i in range(F)],
+                            params, WB, CM)
+    stream = torch.cuda.Stream(device=dev)
+
+    def step():
+        be.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
+        if with_hist:
+            be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
+            if world > 1:
+                allreduce_histogram(hist)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                         # HIP events on the launch stream
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_px = float(world) * F * W * H * args.steps
+    if with_hist:                                          # sanity: the global histogram counts every pixel
+        got = int(hist.sum().item())
+        assert got == 3 * world * F * W * H, f"histogram sum {got} != {3 * world * F * W * H}"
+
+    launches = args.steps * F * max(1, args.row_bands)
+    launch_us = dev_ms * 1e3 / launches                    # avg fused-launch duration incl. gaps
+    alg_bytes = BYTES_PER_PX[args.format] * W * H / max(1, args.row_bands)
+    achieved = alg_bytes / (launch_us * 1e-6) / 1e9        # GB/s
+    traffic = None
+    try:                                                   # PMC-derived HBM bytes per launch (rocprofv3 --pmc,
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:   # tools/parse_pmc.py)
+            traffic = json.load(fh).get(args.format, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+
+    result = {
+        "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
+        "value": round(total_px / 1e6 / elapsed, 1),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
+                        f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}",
+            "frames_per_gpu": F, "width": W, "height": H, "surface": f"rgba_{args.format}",
+            "row_bands": args.row_bands, "out_ring": len(ring),
+            "parallelism": f"frames sharded round-robin over {world} GPU(s); RCCL all-reduce of i64[768] histogram only",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "kernel": "rd_develop_quads", "launch_us": round(launch_us, 2),
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * rawdev.h -- C ABI of librawdev.so: the MI355X (gfx950) drop-in for RawEditor's GPU develop path.
+ *
+ * The library replaces exactly one thing in the reference: `gpu::RenderPipeline`
+ * (/root/reference/src/gpu/pipeline.rs:81-100, :112-737; re-exported gpu/mod.rs:16) together with
+ * the WGSL shader it drives (/root/reference/src/gpu/shaders.rs:14-268).  Every entry point below
+ * names the reference interface it stands in for.  A Rust host binds these with a plain
+ * `extern "C"` block; nothing in the signatures is a torch, HIP or C++ type --
+ * device pointers and streams cross the boundary as `void*` / `const uint16_t*`.
+ *
+ * Conventions
+ *   - every function returns an rd_status (0 = ok, negative = error) unless noted; the message of
+ *     the last error on the calling thread is rd_last_error().  Nothing aborts or throws.
+ *   - host buffers are caller-owned and tightly packed (the reference strips wgpu's 256-byte row
+ *     padding, pipeline.rs:511-521, :595-601); `*_len` arguments are byte lengths and are checked.
+ *   - a pipeline handle may be used from several threads at once (the reference shares
+ *     Arc<RenderPipeline> between the UI thread and a tokio blocking thread, main.rs:1054, :1749).
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute call fails with
+ *     RD_ERR_NO_DEVICE / RD_ERR_HIP.
+ */
+#ifndef RAWDEV_H
+#define RAWDEV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_ABI_VERSION 1
+
+typedef enum rd_status {
+    RD_OK = 0,
+    RD_ERR_INVALID_ARG = -1,
+    RD_ERR_NO_DEVICE = -2,
+    RD_ERR_HIP = -3,
+    RD_ERR_OOM = -4,
+    RD_ERR_UNSUPPORTED = -5
+} rd_status;
+
+/* Output surface formats.  U8 is what the reference renders (Rgba8Unorm, pipeline.rs:322, :454,
+ * :538, :627); F32 is the shader's own return value vec4(color,1.0) (shaders.rs:264-266), the
+ * surface BASELINE.json's north_star asks for; F16 is the 100 MP configuration's surface. */
+typedef enum rd_format {
+    RD_FMT_RGBA_F32 = 0, /* 16 B/px */
+    RD_FMT_RGBA_F16 = 1, /*  8 B/px, IEEE binary16, round-to-nearest-even of the f32 value */
+    RD_FMT_RGBA_U8 = 2   /*  4 B/px, trunc(x*255 + 0.5), alpha 255 */
+} rd_format;
+
+/* state::edit::EditParams (src/state/edit.rs:15-77): ten f32 in this order; #[repr(C)]-compatible. */
+typedef struct rd_edit_params {
+    float exposure;    /* stops, UI range [-5, 5]          (main.rs:1624-1660 for all ranges) */
+    float contrast;    /* UI [-10, 10]; shader divides by 100 (shaders.rs:233) */
+    float highlights;  /* UI [-1, 1] */
+    float shadows;     /* UI [-1, 1] */
+    float whites;      /* UI [0.8, 1.2], default 1.0 */
+    float blacks;      /* UI [0, 0.2] */
+    float vibrance;    /* UI [-1, 1] */
+    float saturation;  /* UI [-100, 100]; shader divides by 100 (shaders.rs:245) */
+    float temperature; /* UI [-1, 1] */
+    float tint;        /* UI [-1, 1] */
+} rd_edit_params;
+
+/* The public fields of RenderPipeline (pipeline.rs:89-96) + dimensions() (:609). */
+typedef struct rd_info {
+    uint32_t width, height;
+    uint32_t preview_width, preview_height;     /* pipeline.rs:125-128 */
+    uint32_t histogram_width, histogram_height; /* pipeline.rs:131-133 */
+    int64_t image_id;
+} rd_info;
+
+typedef struct rd_pipeline rd_pipeline;
+typedef struct rd_batch rd_batch;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int rd_abi_version(void);              /* returns RD_ABI_VERSION (not a status) */
+const char *rd_last_error(void);       /* thread-local, never NULL */
+int rd_device_count(int *count);       /* number of visible HIP devices */
+/* EditParams::default() (edit.rs:81-95): all 0 except whites = 1. */
+void rd_edit_params_default(rd_edit_params *p);
+/* preview / histogram target sizes with the reference's truncating f32 arithmetic (pipeline.rs:125-133). */
+int rd_derived_dims(uint32_t width, uint32_t height, uint32_t *preview_w, uint32_t *preview_h,
+                    uint32_t *hist_w, uint32_t *hist_h);
+size_t rd_format_bytes_per_pixel(uint32_t format); /* 0 for an unknown format */
+
+/* ---- RenderPipeline ------------------------------------------------------------------------ */
+/* RenderPipeline::new (pipeline.rs:114-363).  `cfa` is w*h u16, row-major, no padding
+ * (raw/loader.rs:11-19); it is borrowed for the call and copied to HBM.  `color_matrix` is the
+ * host's row-major [9]; like the reference the rows are consumed as COLUMNS (shaders.rs:209-214). */
+int rd_pipeline_create(int device, int64_t image_id, const uint16_t *cfa, uint32_t width,
+                       uint32_t height, const rd_edit_params *params, const float wb_multipliers[4],
+                       const float color_matrix[9], rd_pipeline **out);
+/* Same, but `cfa_dev` already lives in this device's HBM and is borrowed for the pipeline's
+ * lifetime (batch export keeps frames resident; no copy). */
+int rd_pipeline_create_from_device(int device, int64_t image_id, const uint16_t *cfa_dev,
+                                   uint32_t width, uint32_t height, const rd_edit_params *params,
+                                   const float wb_multipliers[4], const float color_matrix[9],
+                                   rd_pipeline **out);
+/* Drop (Arc count -> 0, main.rs:1028).  NULL is a no-op. */
+void rd_pipeline_destroy(rd_pipeline *p);
+int rd_pipeline_info(const rd_pipeline *p, rd_info *out);
+/* Extension: integer black level subtracted (saturating) before normalisation.
+ * 0 (default) is the reference, which subtracts nothing (shaders.rs:106-110). */
+int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t black_level);
+
+/* update_uniforms (pipeline.rs:367) == update_uniforms_with_zoom(params, 1, 0, 0). */
+int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params);
+/* update_uniforms_with_zoom (pipeline.rs:373-398). */
+int rd_update_uniforms_with_zoom(rd_pipeline *p, const rd_edit_params *params, float zoom,
+                                 float pan_x, float pan_y);
+
+/* render_to_bytes (pipeline.rs:442-522): preview_width x preview_height RGBA8 with the current
+ * uniforms (zoom/pan included). dst_len must be preview_w*preview_h*4. */
+int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
+/* render_full_res_to_bytes (pipeline.rs:526-606): width x height RGBA8, current uniforms. */
+int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
+/* render_to_histogram_bytes (pipeline.rs:615-716): histogram_width x histogram_height RGBA8. */
+int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
+/* calculate_histogram (pipeline.rs:720-736): [R[256], G[256], B[256]] counts of RGBA8 bytes
+ * (alpha ignored), computed on the pipeline's device.  rgba_len is a byte length (multiple of 4). */
+int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_t rgba_len, uint32_t hist[768]);
+
+/* General form of the three renders: any target size and surface format, current uniforms.
+ * `hist` (nullable) receives the fused 3x256 histogram of the 8-bit quantised output -- the same
+ * counts rd_calculate_histogram would give on the U8 surface of this render. */
+int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format, void *dst,
+              size_t dst_len, uint32_t hist[768]);
+/* Device-resident variant: `dst_dev` (and nullable `hist_dev`, 768 x u32) are device pointers on
+ * the pipeline's device; work is enqueued on `stream` (a hipStream_t, NULL = default stream) and
+ * NOT synchronised. */
+int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format,
+                     void *dst_dev, uint32_t *hist_dev, void *stream);
+
+/* ---- batch export (no reference counterpart; BASELINE.json configs 3-5) -------------------- */
+/* One frame of a batch: everything RenderPipeline::new + update_uniforms would be given. */
+typedef struct rd_frame {
+    const uint16_t *cfa_dev; /* w*h u16 in this device's HBM */
+    void *out_dev;           /* w*h*bytes_per_pixel(format) in this device's HBM */
+    rd_edit_params params;
+    float wb_multipliers[4];
+    float color_matrix[9];
+    uint32_t black_level;
+} rd_frame;
+
+/* A batch context owns the per-stream histogram slabs for frames of one size/format on one device. */
+int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format,
+                    uint32_t with_histogram, rd_batch **out);
+void rd_batch_destroy(rd_batch *b);
+/* Enqueue one fused demosaic+develop(+histogram) launch per frame on `stream`, full resolution,
+ * zoom 1 / pan 0 (the export map).  Histogram counts accumulate inside the context in u64.
+ * `row_bands` > 1 splits every frame into that many row-band launches (config 5's tiled
+ * multi-launch); 0 or 1 = one launch per frame.  Not synchronised. */
+int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n_frames, uint32_t row_bands,
+                     void *stream);
+/* Reduce the accumulated histogram into `hist_dev` (768 x u64 on the device: R[256] G[256] B[256])
+ * and reset the accumulator.  Enqueued on `stream`; the multi-GPU sum is the caller's all-reduce. */
+int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);
+
+/* ---- plumbing for hosts without a HIP binding (tests, the Python mirror) -------------------- */
+int rd_device_malloc(int device, size_t bytes, void **out);
+int rd_device_free(int device, void *ptr);
+int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes);
+int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t bytes);
+int rd_device_synchronize(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAWDEV_H */

@@ -221,6 +221,16 @@ void ref_render_f32_rows(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_
             ref_pixel(cfa, w, h, u, tw, th, i, j, pow_mode, out + ((size_t)j * tw + i) * 4);
 }
 
+/* Rows [row0,row1) of the target only; out_band holds (row1-row0)*tw*4 floats. */
+void ref_render_f32_band(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
+                         uint32_t tw, uint32_t th, uint32_t row0, uint32_t row1, int pow_mode,
+                         float *out_band)
+{
+    for (uint32_t j = row0; j < row1; ++j)
+        for (uint32_t i = 0; i < tw; ++i)
+            ref_pixel(cfa, w, h, u, tw, th, i, j, pow_mode, out_band + ((size_t)(j - row0) * tw + i) * 4);
+}
+
 void ref_render_f32(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
                     uint32_t tw, uint32_t th, int pow_mode, float *out)
 {

@@ -65,6 +65,9 @@ void ref_pixel(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *
 void ref_render_f32_rows(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
                          uint32_t tw, uint32_t th, uint32_t row0, uint32_t row1, int pow_mode,
                          float *out);
+void ref_render_f32_band(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
+                         uint32_t tw, uint32_t th, uint32_t row0, uint32_t row1, int pow_mode,
+                         float *out_band);   /* rows [row0,row1) only, band-relative storage */
 void ref_render_f32(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
                     uint32_t tw, uint32_t th, int pow_mode, float *out);
 /* Row-parallel over nthreads pthreads (cpu_baseline leg of bench.py). */

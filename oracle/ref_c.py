@@ -55,6 +55,9 @@ def lib():
         L.ref_derived_dims.argtypes = [C.c_uint32, C.c_uint32] + [u32p] * 4
         L.ref_render_f32.argtypes = [u16p, C.c_uint32, C.c_uint32, UP, C.c_uint32, C.c_uint32, C.c_int, f32p]
         L.ref_render_f32_mt.argtypes = [u16p, C.c_uint32, C.c_uint32, UP, C.c_uint32, C.c_uint32, C.c_int, f32p, C.c_int]
+        L.ref_render_f32_band.argtypes = [u16p, C.c_uint32, C.c_uint32, UP, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_int, f32p]
+        L.ref_render_f32_band.restype = None
         L.ref_pack_u8.argtypes = [f32p, C.c_size_t, u8p]
         L.ref_pack_f16.argtypes = [f32p, C.c_size_t, u16p]
         L.ref_histogram.argtypes = [u8p, C.c_size_t, u32p]
@@ -93,6 +96,19 @@ def render_f32(cfa: np.ndarray, u: RefUniforms, tw=None, th=None, pow_mode=POW_P
     if tw and th:
         lib().ref_render_f32_mt(_ptr(cfa, C.c_uint16), w, h, C.byref(u), tw, th, pow_mode,
                                 _ptr(out, C.c_float), int(nthreads))
+    return out
+
+
+def render_band(cfa: np.ndarray, u: RefUniforms, row0: int, row1: int, tw=None, th=None,
+                pow_mode=POW_PINNED) -> np.ndarray:
+    """Rows [row0,row1) of the target surface only (full-size frames: sample a few bands)."""
+    cfa = np.ascontiguousarray(cfa, np.uint16)
+    h, w = cfa.shape
+    tw = w if tw is None else int(tw)
+    th = h if th is None else int(th)
+    out = np.empty((row1 - row0, tw, 4), np.float32)
+    lib().ref_render_f32_band(_ptr(cfa, C.c_uint16), w, h, C.byref(u), tw, th, row0, row1, pow_mode,
+                              _ptr(out, C.c_float))
     return out
 
 

@@ -1,0 +1,16 @@
+"""raweditor_amd -- MI355X-native develop path for RawEditor (Bayer demosaic + 10-slider colour
+stack + histogram as fused HIP kernels behind the librawdev C ABI, include/rawdev.h).
+
+Host mirror of the reference interface for this path:
+    EditParams      <- state::edit::EditParams   (src/state/edit.rs)
+    RenderPipeline  <- gpu::RenderPipeline       (src/gpu/pipeline.rs)
+    BatchExporter   <- (new) frame-sharded batch export + global histogram
+"""
+from ._lib import (FMT_RGBA_F16, FMT_RGBA_F32, FMT_RGBA_U8, BYTES_PER_PIXEL, RawdevError, device_count)
+from .edit import EditParams, FIELDS, UI_RANGES
+from .pipeline import RenderPipeline, calculate_cam_to_srgb_matrix, derived_dims, IDENTITY_MATRIX
+from .batch import BatchExporter, shard_frames
+
+__all__ = ["EditParams", "RenderPipeline", "BatchExporter", "RawdevError", "shard_frames",
+           "FMT_RGBA_F32", "FMT_RGBA_F16", "FMT_RGBA_U8", "BYTES_PER_PIXEL", "FIELDS", "UI_RANGES",
+           "calculate_cam_to_srgb_matrix", "derived_dims", "device_count", "IDENTITY_MATRIX"]

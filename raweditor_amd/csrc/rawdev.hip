@@ -1,0 +1,583 @@
+// rawdev.hip -- host side of librawdev.so: the extern "C" entry points of include/rawdev.h.
+//
+// Stands in for gpu::RenderPipeline (reference src/gpu/pipeline.rs:112-737).  Differences that
+// are deliberate and MI355X-first:
+//   * the reference creates a wgpu Instance+Device per image (pipeline.rs:144-169) and a target
+//     texture + MAP_READ buffer per frame (:444-477); here a pipeline keeps one HBM copy of the
+//     CFA plane, one reusable output buffer and one stream;
+//   * uniforms are kernel arguments (no uniform buffer, no write_buffer);
+//   * linear buffers, not textures: no 8192-px texture limit (pipeline.rs:164), so 100 MP frames
+//     need no special casing.
+// There is no CPU compute path in this file: every render is a gfx950 kernel launch.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "../../include/rawdev.h"
+#include "rd_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int rd_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RD_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return rd_fail(e_ == hipErrorOutOfMemory ? RD_ERR_OOM                                 \
+                           : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? RD_ERR_NO_DEVICE \
+                                                                                     : RD_ERR_HIP, \
+                           "%s failed: %s", #call, hipGetErrorString(e_));                        \
+    } while (0)
+
+extern "C" int rd_abi_version(void) { return RD_ABI_VERSION; }
+extern "C" const char *rd_last_error(void) { return g_err; }
+
+extern "C" int rd_device_count(int *count)
+{
+    if (!count) return rd_fail(RD_ERR_INVALID_ARG, "rd_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return rd_fail(RD_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RD_OK;
+}
+
+extern "C" void rd_edit_params_default(rd_edit_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);   // edit.rs:81-95
+    p->whites = 1.0f;
+}
+
+extern "C" int rd_derived_dims(uint32_t w, uint32_t h, uint32_t *pw, uint32_t *ph, uint32_t *hw, uint32_t *hh)
+{
+    if (!w || !h || !pw || !ph || !hw || !hh) return rd_fail(RD_ERR_INVALID_ARG, "rd_derived_dims: bad argument");
+    // pipeline.rs:125-133, same truncating f32 arithmetic
+    const float aspect = (float)w / (float)h;
+    const uint32_t preview_w = w < 1280u ? w : 1280u;
+    *pw = preview_w;
+    *ph = (uint32_t)((float)preview_w / aspect);
+    *hw = 128u;
+    *hh = (uint32_t)((float)128u / aspect);
+    return RD_OK;
+}
+
+extern "C" size_t rd_format_bytes_per_pixel(uint32_t f)
+{
+    return f == RD_FMT_RGBA_F32 ? 16 : f == RD_FMT_RGBA_F16 ? 8 : f == RD_FMT_RGBA_U8 ? 4 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device bookkeeping
+// ------------------------------------------------------------------------------------------------
+struct rd_devguard {
+    int prev = -1;
+    bool ok = false;
+    explicit rd_devguard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~rd_devguard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static int rd_check_device(int device, int *n_cu)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return rd_fail(RD_ERR_NO_DEVICE, "no HIP device visible (librawdev has no CPU fallback)");
+    if (device < 0 || device >= n) return rd_fail(RD_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    RD_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rd_fail(RD_ERR_UNSUPPORTED, "device %d is %s; librawdev ships gfx950 code only", device, prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    return RD_OK;
+}
+
+static uint32_t rd_env_u32(const char *name, uint32_t dflt)
+{
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    long v = strtol(s, nullptr, 10);
+    return v > 0 ? (uint32_t)v : dflt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch plumbing shared by pipelines and batches
+// ------------------------------------------------------------------------------------------------
+// Does the reference's f32 pixel map (shaders.rs:31-57, :184-187) reduce to px=i, py=j when the
+// target is the frame itself at zoom 1 / pan 0?  (It does for every size we have seen; the check
+// keeps the quad kernel honest for sizes where f32 rounding could break it.)
+static bool rd_identity_map(uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        float s = ((float)i + 0.5f) / (float)n;
+        float t = ((s - 0.5f) / 1.0f - 0.0f) + 0.5f;
+        if (!(t >= 0.0f && t <= 1.0f)) return false;
+        if ((int32_t)(t * (float)n) != (int32_t)i) return false;
+    }
+    return true;
+}
+
+struct rd_launch_cfg {
+    int n_cu = 256;
+    uint32_t wg_per_cu_hist = 1;     // 96 KiB of LDS per workgroup
+    uint32_t wg_per_cu_plain = 2;    // 2 x 1024 threads = the CU's 32 waves
+};
+
+template <int FMT, bool HIST>
+static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t unit0,
+                              uint32_t unit1, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
+                              unsigned long long *slab64, hipStream_t s)
+{
+    const uint32_t qpr = W >> 1;
+    const uint32_t stride = blocks * RD_BLOCK;
+    hipLaunchKernelGGL((rd_develop_quads<FMT, HIST>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+                       unit0, unit1, stride / qpr, stride % qpr, u, slab32, slab64);
+}
+
+template <int FMT, bool HIST>
+static void rd_launch_map_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t tw,
+                            uint32_t th, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
+                            unsigned long long *slab64, hipStream_t s)
+{
+    hipLaunchKernelGGL((rd_develop_map<FMT, HIST>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H, tw,
+                       th, u, slab32, slab64);
+}
+
+#define RD_DISPATCH(fn, fmt, hist, ...)                                                           \
+    do {                                                                                          \
+        if (hist) {                                                                               \
+            if (fmt == RD_FMT_RGBA_F32) fn<RD_FMT_RGBA_F32, true>(__VA_ARGS__);                   \
+            else if (fmt == RD_FMT_RGBA_F16) fn<RD_FMT_RGBA_F16, true>(__VA_ARGS__);              \
+            else fn<RD_FMT_RGBA_U8, true>(__VA_ARGS__);                                           \
+        } else {                                                                                  \
+            if (fmt == RD_FMT_RGBA_F32) fn<RD_FMT_RGBA_F32, false>(__VA_ARGS__);                  \
+            else if (fmt == RD_FMT_RGBA_F16) fn<RD_FMT_RGBA_F16, false>(__VA_ARGS__);             \
+            else fn<RD_FMT_RGBA_U8, false>(__VA_ARGS__);                                          \
+        }                                                                                         \
+    } while (0)
+
+static uint32_t rd_blocks_for(const rd_launch_cfg &cfg, uint64_t items, bool hist)
+{
+    uint64_t need = (items + RD_BLOCK - 1) / RD_BLOCK;
+    uint64_t cap = (uint64_t)cfg.n_cu * (hist ? cfg.wg_per_cu_hist : cfg.wg_per_cu_plain);
+    if (cap > RD_MAX_BLOCKS) cap = RD_MAX_BLOCKS;
+    uint64_t b = need < cap ? need : cap;
+    return b ? (uint32_t)b : 1u;
+}
+
+static size_t rd_align_for(uint32_t fmt) { return fmt == RD_FMT_RGBA_F32 ? 16 : fmt == RD_FMT_RGBA_F16 ? 8 : 4; }
+
+// Enqueue one render of (cfa, W, H) to a tw x th target.  Returns the number of workgroups used
+// (the slab rows written) through *blocks_out.  use_quads selects the export kernel.
+static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint32_t W, uint32_t H,
+                             uint32_t tw, uint32_t th, uint32_t fmt, void *out, const rd_ku &u,
+                             bool use_quads, uint32_t unit0, uint32_t unit1, bool hist,
+                             uint32_t *slab32, unsigned long long *slab64, uint32_t fixed_blocks,
+                             hipStream_t s, uint32_t *blocks_out)
+{
+    uint32_t blocks;
+    if (use_quads) {
+        const uint64_t items = (uint64_t)(unit1 - unit0) * (W >> 1);
+        if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
+        blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
+        RD_DISPATCH(rd_launch_quads_t, fmt, hist, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, s);
+    } else {
+        const uint64_t items = (uint64_t)tw * th;
+        if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "target too large for 32-bit pixel index");
+        blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
+        RD_DISPATCH(rd_launch_map_t, fmt, hist, cfa, out, W, H, tw, th, blocks, u, slab32, slab64, s);
+    }
+    RD_HIP(hipGetLastError());
+    if (blocks_out) *blocks_out = blocks;
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_pipeline
+// ------------------------------------------------------------------------------------------------
+struct rd_pipeline {
+    int device = 0;
+    rd_info info{};
+    rd_launch_cfg cfg;
+    const uint16_t *cfa = nullptr;
+    bool owns_cfa = false;
+    bool identity_ok = false;
+    rd_edit_params params{};
+    float wb[4]{}, cm[9]{};
+    float zoom = 1.0f, pan_x = 0.0f, pan_y = 0.0f;
+    uint32_t black_level = 0;
+    // scratch
+    hipStream_t stream = nullptr;
+    void *out_buf = nullptr; size_t out_cap = 0;
+    uint32_t *slab32 = nullptr;       // RD_MAX_BLOCKS x 768
+    uint32_t *hist_dev = nullptr;     // 768
+    std::mutex mu;                    // uniforms + scratch (Send + Sync like Arc<RenderPipeline>)
+};
+
+static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bool cfa_on_device,
+                           uint32_t w, uint32_t h, const rd_edit_params *params, const float wb[4],
+                           const float cm[9], rd_pipeline **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!cfa || !params || !wb || !cm) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
+    if ((uint64_t)w * h >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u exceeds 2^32 pixels", w, h);
+    int n_cu = 0;
+    int rc = rd_check_device(device, &n_cu);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+
+    rd_pipeline *p = new (std::nothrow) rd_pipeline;
+    if (!p) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    p->device = device;
+    p->cfg.n_cu = n_cu;
+    p->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
+    p->info.width = w; p->info.height = h; p->info.image_id = image_id;
+    rd_derived_dims(w, h, &p->info.preview_width, &p->info.preview_height, &p->info.histogram_width,
+                    &p->info.histogram_height);
+    p->params = *params;
+    memcpy(p->wb, wb, sizeof p->wb);
+    memcpy(p->cm, cm, sizeof p->cm);
+    p->identity_ok = rd_identity_map(w) && rd_identity_map(h);
+
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->slab32, (size_t)RD_MAX_BLOCKS * 768 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->hist_dev, 768 * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        if (cfa_on_device) {
+            p->cfa = cfa;
+        } else {
+            void *d = nullptr;
+            e = hipMalloc(&d, (size_t)w * h * sizeof(uint16_t));
+            if (e == hipSuccess) {
+                p->cfa = (const uint16_t *)d; p->owns_cfa = true;
+                e = hipMemcpy(d, cfa, (size_t)w * h * sizeof(uint16_t), hipMemcpyHostToDevice);
+            }
+        }
+    }
+    if (e != hipSuccess) {
+        int code = rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "pipeline setup failed: %s", hipGetErrorString(e));
+        rd_pipeline_destroy(p);
+        return code;
+    }
+    *out = p;
+    return RD_OK;
+}
+
+extern "C" int rd_pipeline_create(int device, int64_t image_id, const uint16_t *cfa, uint32_t w, uint32_t h,
+                                  const rd_edit_params *params, const float wb[4], const float cm[9],
+                                  rd_pipeline **out)
+{
+    return rd_pipeline_new(device, image_id, cfa, false, w, h, params, wb, cm, out);
+}
+
+extern "C" int rd_pipeline_create_from_device(int device, int64_t image_id, const uint16_t *cfa_dev, uint32_t w,
+                                              uint32_t h, const rd_edit_params *params, const float wb[4],
+                                              const float cm[9], rd_pipeline **out)
+{
+    return rd_pipeline_new(device, image_id, cfa_dev, true, w, h, params, wb, cm, out);
+}
+
+extern "C" void rd_pipeline_destroy(rd_pipeline *p)
+{
+    if (!p) return;
+    {
+        rd_devguard g(p->device);
+        if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+        if (p->owns_cfa && p->cfa) (void)hipFree((void *)p->cfa);
+        if (p->out_buf) (void)hipFree(p->out_buf);
+        if (p->slab32) (void)hipFree(p->slab32);
+        if (p->hist_dev) (void)hipFree(p->hist_dev);
+    }
+    delete p;
+}
+
+extern "C" int rd_pipeline_info(const rd_pipeline *p, rd_info *out)
+{
+    if (!p || !out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    *out = p->info;
+    return RD_OK;
+}
+
+extern "C" int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t bl)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->black_level = bl;
+    return RD_OK;
+}
+
+extern "C" int rd_update_uniforms_with_zoom(rd_pipeline *p, const rd_edit_params *params, float zoom, float pan_x,
+                                            float pan_y)
+{
+    if (!p || !params) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->params = *params;     // wb / matrix are preserved, as in pipeline.rs:375-381
+    p->zoom = zoom; p->pan_x = pan_x; p->pan_y = pan_y;
+    return RD_OK;
+}
+
+extern "C" int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params)
+{
+    return rd_update_uniforms_with_zoom(p, params, 1.0f, 0.0f, 0.0f);   // pipeline.rs:367-369
+}
+
+// caller holds p->mu and has the device set
+static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_t fmt, void *dst_dev,
+                               uint32_t *hist_dev, hipStream_t s)
+{
+    if (!tw || !th) return rd_fail(RD_ERR_INVALID_ARG, "empty target %ux%u", tw, th);
+    if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    if ((uintptr_t)dst_dev % rd_align_for(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "dst is not %zu-byte aligned", rd_align_for(fmt));
+    const uint32_t W = p->info.width, H = p->info.height;
+    const rd_ku u = rd_make_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level);
+    const bool quads = tw == W && th == H && p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f &&
+                       (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
+                       !getenv("RD_FORCE_MAP");
+    uint32_t blocks = 0;
+    int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
+                               hist_dev != nullptr, p->slab32, nullptr, 0, s, &blocks);
+    if (rc) return rc;
+    if (hist_dev) {
+        hipLaunchKernelGGL(rd_reduce_slab32, dim3(3), dim3(256), 0, s, p->slab32, blocks, hist_dev);
+        RD_HIP(hipGetLastError());
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst_dev,
+                                uint32_t *hist_dev, void *stream)
+{
+    if (!p || !dst_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    rd_devguard g(p->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+    std::lock_guard<std::mutex> lk(p->mu);   // the slab is shared scratch
+    return rd_pipeline_enqueue(p, out_w, out_h, fmt, dst_dev, hist_dev, (hipStream_t)stream);
+}
+
+extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst, size_t dst_len,
+                         uint32_t hist[768])
+{
+    if (!p || !dst) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    const size_t bpp = rd_format_bytes_per_pixel(fmt);
+    if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    const size_t need = (size_t)out_w * out_h * bpp;
+    if (!need) return rd_fail(RD_ERR_INVALID_ARG, "empty target %ux%u", out_w, out_h);
+    if (dst_len != need) return rd_fail(RD_ERR_INVALID_ARG, "dst_len %zu != %ux%ux%zu = %zu", dst_len, out_w, out_h, bpp, need);
+    rd_devguard g(p->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->out_cap < need) {
+        if (p->out_buf) { (void)hipFree(p->out_buf); p->out_buf = nullptr; p->out_cap = 0; }
+        RD_HIP(hipMalloc(&p->out_buf, need));
+        p->out_cap = need;
+    }
+    int rc = rd_pipeline_enqueue(p, out_w, out_h, fmt, p->out_buf, hist ? p->hist_dev : nullptr, p->stream);
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(dst, p->out_buf, need, hipMemcpyDeviceToHost, p->stream));
+    if (hist) RD_HIP(hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+    RD_HIP(hipStreamSynchronize(p->stream));
+    return RD_OK;
+}
+
+extern "C" int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    return rd_render(p, p->info.preview_width, p->info.preview_height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
+}
+
+extern "C" int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    return rd_render(p, p->info.width, p->info.height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
+}
+
+extern "C" int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    return rd_render(p, p->info.histogram_width, p->info.histogram_height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
+}
+
+extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_t rgba_len, uint32_t hist[768])
+{
+    if (!p || !hist || (!rgba && rgba_len)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (rgba_len % 4) return rd_fail(RD_ERR_INVALID_ARG, "rgba_len %zu is not a multiple of 4", rgba_len);
+    const size_t npx = rgba_len / 4;
+    if (npx >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "too many pixels");
+    if (!npx) { memset(hist, 0, 768 * sizeof(uint32_t)); return RD_OK; }
+    rd_devguard g(p->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->out_cap < rgba_len) {
+        if (p->out_buf) { (void)hipFree(p->out_buf); p->out_buf = nullptr; p->out_cap = 0; }
+        RD_HIP(hipMalloc(&p->out_buf, rgba_len));
+        p->out_cap = rgba_len;
+    }
+    RD_HIP(hipMemcpyAsync(p->out_buf, rgba, rgba_len, hipMemcpyHostToDevice, p->stream));
+    const uint32_t blocks = rd_blocks_for(p->cfg, npx, true);
+    hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, p->stream, (const uint32_t *)p->out_buf,
+                       (uint32_t)npx, p->slab32);
+    hipLaunchKernelGGL(rd_reduce_slab32, dim3(3), dim3(256), 0, p->stream, p->slab32, blocks, p->hist_dev);
+    RD_HIP(hipGetLastError());
+    RD_HIP(hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+    RD_HIP(hipStreamSynchronize(p->stream));
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_batch
+// ------------------------------------------------------------------------------------------------
+struct rd_batch {
+    int device = 0;
+    uint32_t w = 0, h = 0, fmt = 0;
+    bool hist = false;
+    bool identity_ok = false;
+    rd_launch_cfg cfg;
+    uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
+    unsigned long long *slab64 = nullptr;      // blocks x 768
+};
+
+extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
+                               rd_batch **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
+    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
+    if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    const uint64_t items = (uint64_t)(h / 2u + 1u) * (w >> 1);
+    if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
+    int n_cu = 0;
+    int rc = rd_check_device(device, &n_cu);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rd_batch *b = new (std::nothrow) rd_batch;
+    if (!b) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    b->device = device; b->w = w; b->h = h; b->fmt = fmt; b->hist = with_histogram != 0;
+    b->cfg.n_cu = n_cu;
+    b->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
+    b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
+    if (!b->identity_ok) { delete b; return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h); }
+    b->blocks = rd_blocks_for(b->cfg, items, b->hist);
+    if (b->hist) {
+        hipError_t e = hipMalloc((void **)&b->slab64, (size_t)b->blocks * 768 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(b->slab64, 0, (size_t)b->blocks * 768 * sizeof(unsigned long long));
+        if (e != hipSuccess) { delete b; return rd_fail(RD_ERR_OOM, "slab allocation failed: %s", hipGetErrorString(e)); }
+    }
+    *out = b;
+    return RD_OK;
+}
+
+extern "C" void rd_batch_destroy(rd_batch *b)
+{
+    if (!b) return;
+    {
+        rd_devguard g(b->device);
+        if (b->slab64) { (void)hipDeviceSynchronize(); (void)hipFree(b->slab64); }
+    }
+    delete b;
+}
+
+extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, uint32_t row_bands, void *stream)
+{
+    if (!b || (!frames && n)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    const uint32_t units = b->h / 2u + 1u;
+    uint32_t bands = row_bands ? row_bands : 1u;
+    if (bands > units) bands = units;
+    for (size_t f = 0; f < n; ++f) {
+        const rd_frame &fr = frames[f];
+        if (!fr.cfa_dev || !fr.out_dev) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f);
+        if ((uintptr_t)fr.cfa_dev % 4u) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f);
+        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f);
+        const rd_ku u = rd_make_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level);
+        for (uint32_t k = 0; k < bands; ++k) {
+            const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
+            const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
+            int rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0,
+                                       u1, b->hist, nullptr, b->slab64, b->blocks, (hipStream_t)stream, nullptr);
+            if (rc) return rc;
+        }
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
+{
+    if (!b || !hist_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    hipLaunchKernelGGL(rd_reduce_slab64, dim3(3), dim3(256), 0, (hipStream_t)stream, b->slab64, b->blocks,
+                       (unsigned long long *)hist_dev);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plumbing
+// ------------------------------------------------------------------------------------------------
+extern "C" int rd_device_malloc(int device, size_t bytes, void **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return RD_OK;
+}
+
+extern "C" int rd_device_free(int device, void *ptr)
+{
+    if (!ptr) return RD_OK;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipFree(ptr));
+    return RD_OK;
+}
+
+extern "C" int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes)
+{
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice));
+    return RD_OK;
+}
+
+extern "C" int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t bytes)
+{
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_device_synchronize(int device)
+{
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipDeviceSynchronize());
+    return RD_OK;
+}

@@ -1,0 +1,324 @@
+// rd_kernels.h -- gfx950 kernels of the develop path (compiled only with --offload-arch=gfx950).
+//
+//   rd_develop_quads : the export hot path.  Full-resolution identity map (shaders.rs:184-187 with
+//                      zoom 1 / pan 0), nearest-neighbour demosaic (shaders.rs:104-169), colour
+//                      stack + gamma + clamp (shaders.rs:192-266), surface store and the 3x256
+//                      histogram (pipeline.rs:720-736) in ONE launch per frame.
+//   rd_develop_map   : any target size / zoom / pan (preview 1280 px, histogram 128 px; the
+//                      point-sampling map of shaders.rs:23-60), same arithmetic, one pixel per lane.
+//   rd_hist_u8       : calculate_histogram on an RGBA8 buffer (pipeline.rs:720-736).
+//   rd_reduce_slab*  : fold the per-workgroup histogram slabs.
+//
+// Why there is no LDS stencil tile: the reference's demosaic only ever reads
+// the 2x2 block {rows 2k-1, 2k} x {cols 2q, 2q+1} for the four output pixels of that same block
+// (selection table of shaders.rs:127-155 with the py+1 parity shift).  One lane owns one such block:
+// every CFA sample is loaded from HBM exactly once, straight into a register, and the four output
+// pixels need only THREE colour evaluations (the odd-row pair is the same triple; the even-row
+// pair shares r and g).  LDS is spent on the histogram instead.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rd_math.h"
+#include "rd_uniforms.h"
+
+#define RD_BLOCK 1024       // 16 waves: one workgroup per CU, 4 waves per SIMD
+#define RD_MAX_BLOCKS 1024  // slab capacity (workgroups per launch)
+#define RD_HK 32            // histogram copies per bin = LDS banks: lane l adds into copy l%32
+
+typedef float rd_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t rd_u2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
+
+struct rd_rgb { float r, g, b; };
+
+// ---------------------------------------------------------------------------------------------
+// shaders.rs:192-266 on one demosaiced triple.  Literal operation order of the WGSL text; this TU
+// is compiled with -ffp-contract=off so nothing here fuses.  `/` is the IEEE-correct divide.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rd_dot709(float r, float g, float b)
+{
+    return ((r * 0.2126f) + (g * 0.7152f)) + (b * 0.0722f);
+}
+
+__device__ __forceinline__ rd_rgb rd_colour(const rd_ku &u, float r, float g, float b)
+{
+    r = r * u.wb_r; g = g * u.wb_g; b = b * u.wb_b;                    // :195
+    r = r * u.kr; b = b * u.kb; g = g * u.kg;                          // :200-205
+    float x = ((u.m[0] * r) + (u.m[3] * g)) + (u.m[6] * b);            // :209-214 (columns)
+    float y = ((u.m[1] * r) + (u.m[4] * g)) + (u.m[7] * b);
+    float z = ((u.m[2] * r) + (u.m[5] * g)) + (u.m[8] * b);
+    r = x * u.em; g = y * u.em; b = z * u.em;                          // :217-218
+    float L = rd_dot709(r, g, b);                                      // :222
+    float hl = 1.0f + (L * u.highlights);                              // :226
+    r = r * hl; g = g * hl; b = b * hl;
+    float sh = 1.0f + ((1.0f - L) * u.shadows);                        // :230
+    r = r * sh; g = g * sh; b = b * sh;
+    r = (r - 0.5f) * u.cf + 0.5f;                                      // :233-234
+    g = (g - 0.5f) * u.cf + 0.5f;
+    b = (b - 0.5f) * u.cf + 0.5f;
+    r = (r - u.blacks) / u.den;                                        // :239
+    g = (g - u.blacks) / u.den;
+    b = (b - u.blacks) / u.den;
+    float Y = rd_dot709(r, g, b);                                      // :243
+    float ys = Y * u.oms;                                              // mix(Y, c, s) :247
+    r = ys + r * u.s; g = ys + g * u.s; b = ys + b * u.s;
+    float sat = __builtin_fmaxf(r, __builtin_fmaxf(g, b)) - __builtin_fminf(r, __builtin_fminf(g, b)); // :251
+    float va = u.vibrance * (1.0f - sat);                              // :254
+    float Y2 = rd_dot709(r, g, b);                                     // :256
+    float a2 = 1.0f + va;
+    float yv = Y2 * (1.0f - a2);                                       // mix(Y2, c, 1+va) :257
+    r = yv + r * a2; g = yv + g * a2; b = yv + b * a2;
+    rd_rgb o;                                                          // :261-264
+    o.r = rd_gamma_clamp(r);
+    o.g = rd_gamma_clamp(g);
+    o.b = rd_gamma_clamp(b);
+    return o;
+}
+
+// f32(raw)/4096 (shaders.rs:106-110, :167-168) with the optional integer black level.
+__device__ __forceinline__ float rd_norm(uint32_t raw, uint32_t bl)
+{
+    raw = raw > bl ? raw - bl : 0u;
+    return (float)raw * (1.0f / 4096.0f);
+}
+
+// Rgba8Unorm quantisation (pipeline.rs:322), pinned as trunc(x*255 + 0.5).
+__device__ __forceinline__ uint32_t rd_q8(float x) { return (uint32_t)(x * 255.0f + 0.5f); }
+
+// ---------------------------------------------------------------------------------------------
+// Histogram: RD_HK private copies of every bin in LDS, copy = lane % RD_HK, so the 32 lanes of a
+// ds_add_u32 lane group always hit 32 different banks whatever the image content (a flat frame
+// would otherwise serialise 64-deep on one address).  Flushed once per workgroup, WITHOUT global
+// atomics, into that workgroup's slab row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rd_hist_zero(uint32_t *lh)
+{
+    for (uint32_t i = threadIdx.x; i < 768u * RD_HK; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void rd_hist_add(uint32_t *lh, uint32_t copy, uint32_t qr, uint32_t qg,
+                                            uint32_t qb, uint32_t inc)
+{
+    atomicAdd(&lh[(qr)*RD_HK + copy], inc);
+    atomicAdd(&lh[(256u + qg) * RD_HK + copy], inc);
+    atomicAdd(&lh[(512u + qb) * RD_HK + copy], inc);
+}
+
+__device__ __forceinline__ void rd_hist_flush(const uint32_t *lh, uint32_t *slab32,
+                                              unsigned long long *slab64)
+{
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 768u; t += blockDim.x) {
+        uint32_t sum = 0;
+#pragma unroll 8
+        for (uint32_t i = 0; i < RD_HK; ++i) sum += lh[t * RD_HK + ((t + i) & (RD_HK - 1))];
+        if (slab64) slab64[(size_t)blockIdx.x * 768u + t] += sum;   // batch: u64, private row
+        else slab32[(size_t)blockIdx.x * 768u + t] = sum;            // single frame: overwrite
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Surface stores.  FMT is an rd_format.  `px` is a pixel index into the tightly packed surface.
+// ---------------------------------------------------------------------------------------------
+template <int FMT>
+__device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &c, uint32_t qr,
+                                            uint32_t qg, uint32_t qb)
+{
+    if (FMT == RD_FMT_RGBA_F32) {
+        rd_f4 v = { c.r, c.g, c.b, 1.0f };
+        __builtin_nontemporal_store(v, reinterpret_cast<rd_f4 *>(out) + px);
+    } else if (FMT == RD_FMT_RGBA_F16) {
+        rd_h2 lo = { (_Float16)c.r, (_Float16)c.g };
+        rd_h2 hi = { (_Float16)c.b, (_Float16)1.0f };
+        rd_u2 v = { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
+        __builtin_nontemporal_store(v, reinterpret_cast<rd_u2 *>(out) + px);
+    } else {
+        uint32_t v = qr | (qg << 8) | (qb << 16) | 0xff000000u;
+        __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(out) + px);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rd_develop_quads -- the export hot path.
+//
+// Work unit u (0 <= u <= H/2) = CFA/output rows a = 2u-1 and b = 2u (a = -1 and b = H do not
+// exist and are skipped); item = (unit, q) owns columns 2q, 2q+1.  With A,B = cfa[a][2q..2q+1]
+// and C,D = cfa[b][2q..2q+1] (row indices clamped to the image, which reproduces get_neighbor's
+// edge clamp for the first and last row) the selection table of shaders.rs:127-155 gives
+//     row a (py odd),  both columns : (r,g,b) = (C, A, B)
+//     row b (py even), column 2q    : (r,g,b) = (C, D, A)     <- blue taken from a green site
+//     row b (py even), column 2q+1  : (r,g,b) = (C, D, B)
+// Requires W even and cfa 4-byte aligned (the host falls back to rd_develop_map otherwise).
+// Items are dealt grid-stride so consecutive lanes read/write consecutive addresses; the (unit,q)
+// pair is advanced incrementally (no per-item division); the next item's two loads are issued
+// before the current item's arithmetic and stores so a load never waits behind a younger store.
+// ---------------------------------------------------------------------------------------------
+template <int FMT, bool HIST>
+__global__ void __launch_bounds__(RD_BLOCK)
+rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
+                 uint32_t unit0, uint32_t unit1, uint32_t stride_units, uint32_t stride_rem,
+                 rd_ku u, uint32_t *slab32, unsigned long long *slab64)
+{
+    __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
+    if (HIST) rd_hist_zero(lh);
+
+    const uint32_t qpr = W >> 1;                       // items per unit
+    const uint32_t total = (unit1 - unit0) * qpr;      // < 2^32: checked on the host
+    const uint32_t copy = threadIdx.x & (RD_HK - 1);
+    uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;    // == stride_units*qpr + stride_rem
+    uint32_t unit = unit0 + item / qpr;
+    uint32_t q = item % qpr;
+
+    uint32_t top = 0, bot = 0;
+    if (item < total) {
+        uint32_t ra = unit ? 2u * unit - 1u : 0u;
+        uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
+        top = *reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W + 2u * q);
+        bot = *reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W + 2u * q);
+    }
+    while (item < total) {
+        // ---- prefetch the next item ----
+        uint32_t nitem = item + stride;
+        uint32_t nunit = unit + stride_units, nq = q + stride_rem;
+        if (nq >= qpr) { nq -= qpr; nunit += 1u; }
+        uint32_t ntop = 0, nbot = 0;
+        if (nitem < total) {
+            uint32_t ra = nunit ? 2u * nunit - 1u : 0u;
+            uint32_t rb = 2u * nunit < H ? 2u * nunit : H - 1u;
+            ntop = *reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W + 2u * nq);
+            nbot = *reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W + 2u * nq);
+        }
+        // ---- this item ----
+        const bool has_a = unit != 0u;
+        const bool has_b = 2u * unit < H;
+        const float A = rd_norm(top & 0xffffu, u.black_level), B = rd_norm(top >> 16, u.black_level);
+        const float C = rd_norm(bot & 0xffffu, u.black_level), D = rd_norm(bot >> 16, u.black_level);
+        if (has_a) {
+            const rd_rgb c1 = rd_colour(u, C, A, B);
+            uint32_t qr = 0, qg = 0, qb = 0;
+            if (HIST || FMT == RD_FMT_RGBA_U8) { qr = rd_q8(c1.r); qg = rd_q8(c1.g); qb = rd_q8(c1.b); }
+            const size_t px = (size_t)(2u * unit - 1u) * W + 2u * q;
+            rd_store_px<FMT>(out, px, c1, qr, qg, qb);
+            rd_store_px<FMT>(out, px + 1, c1, qr, qg, qb);
+            if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 2u);
+        }
+        if (has_b) {
+            const rd_rgb c2 = rd_colour(u, C, D, A);
+            const rd_rgb c3 = rd_colour(u, C, D, B);
+            uint32_t qr2 = 0, qg2 = 0, qb2 = 0, qr3 = 0, qg3 = 0, qb3 = 0;
+            if (HIST || FMT == RD_FMT_RGBA_U8) {
+                qr2 = rd_q8(c2.r); qg2 = rd_q8(c2.g); qb2 = rd_q8(c2.b);
+                qr3 = rd_q8(c3.r); qg3 = rd_q8(c3.g); qb3 = rd_q8(c3.b);
+            }
+            const size_t px = (size_t)(2u * unit) * W + 2u * q;
+            rd_store_px<FMT>(out, px, c2, qr2, qg2, qb2);
+            rd_store_px<FMT>(out, px + 1, c3, qr3, qg3, qb3);
+            if (HIST) {
+                rd_hist_add(lh, copy, qr2, qg2, qb2, 1u);
+                rd_hist_add(lh, copy, qr3, qg3, qb3, 1u);
+            }
+        }
+        item = nitem; unit = nunit; q = nq; top = ntop; bot = nbot;
+    }
+    if (HIST) rd_hist_flush(lh, slab32, slab64);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rd_develop_map -- general target (tw x th), zoom and pan: one output pixel per lane.
+// vs_main evaluated at the pixel centre (shaders.rs:31-57), bounds test (:174-178), trunc to
+// pixel_coords (:184-187), then the per-pixel demosaic with get_neighbor's clamps.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rd_tap(const uint16_t *cfa, int32_t W, int32_t H, int32_t x,
+                                        int32_t y, uint32_t bl)
+{
+    x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+    return rd_norm(cfa[(size_t)y * (size_t)W + (size_t)x], bl);
+}
+
+template <int FMT, bool HIST>
+__global__ void __launch_bounds__(RD_BLOCK)
+rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
+               uint32_t tw, uint32_t th, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
+{
+    __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
+    if (HIST) rd_hist_zero(lh);
+    const uint32_t copy = threadIdx.x & (RD_HK - 1);
+    const uint32_t total = tw * th;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const uint32_t j = idx / tw, i = idx - j * tw;
+        const float sx = ((float)i + 0.5f) / (float)tw;
+        const float sy = ((float)j + 0.5f) / (float)th;
+        const float tx = ((sx - 0.5f) / u.zoom - u.pan_x) + 0.5f;
+        const float ty = ((sy - 0.5f) / u.zoom - u.pan_y) + 0.5f;
+        rd_rgb c = { 0.0f, 0.0f, 0.0f };
+        if (tx >= 0.0f && tx <= 1.0f && ty >= 0.0f && ty <= 1.0f) {
+            int32_t px = (int32_t)(tx * (float)W);
+            int32_t py = (int32_t)(ty * (float)H);
+            px = px > (int32_t)W - 1 ? (int32_t)W - 1 : px;
+            py = py > (int32_t)H - 1 ? (int32_t)H - 1 : py;
+            const float n = rd_tap(cfa, W, H, px, py, u.black_level);
+            const bool even_row = ((py + 1) & 1) == 0;   // shaders.rs:115-116
+            const bool even_col = (px & 1) == 0;
+            float r, g, b;
+            if (even_row) {
+                if (even_col) { g = n; b = rd_tap(cfa, W, H, px + 1, py, u.black_level); r = rd_tap(cfa, W, H, px, py + 1, u.black_level); }
+                else          { b = n; g = rd_tap(cfa, W, H, px - 1, py, u.black_level); r = rd_tap(cfa, W, H, px - 1, py + 1, u.black_level); }
+            } else {
+                if (even_col) { r = n; g = rd_tap(cfa, W, H, px + 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
+                else          { g = n; r = rd_tap(cfa, W, H, px - 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
+            }
+            c = rd_colour(u, r, g, b);
+        }
+        uint32_t qr = 0, qg = 0, qb = 0;
+        if (HIST || FMT == RD_FMT_RGBA_U8) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }
+        rd_store_px<FMT>(out, idx, c, qr, qg, qb);
+        if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 1u);
+    }
+    if (HIST) rd_hist_flush(lh, slab32, slab64);
+}
+
+// calculate_histogram (pipeline.rs:720-736) on an RGBA8 buffer of npx pixels.
+__global__ void __launch_bounds__(RD_BLOCK)
+rd_hist_u8(const uint32_t *__restrict__ rgba, uint32_t npx, uint32_t *slab32)
+{
+    __shared__ uint32_t lh[768 * RD_HK];
+    rd_hist_zero(lh);
+    const uint32_t copy = threadIdx.x & (RD_HK - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < npx; idx += stride) {
+        const uint32_t v = rgba[idx];
+        rd_hist_add(lh, copy, v & 0xffu, (v >> 8) & 0xffu, (v >> 16) & 0xffu, 1u);
+    }
+    rd_hist_flush(lh, slab32, nullptr);
+}
+
+// out32[bin] = sum over workgroups of slab32[wg][bin]   (launch: 3 x 256 threads)
+__global__ void rd_reduce_slab32(const uint32_t *__restrict__ slab32, uint32_t nblocks,
+                                 uint32_t *__restrict__ out32)
+{
+    const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= 768u) return;
+    uint32_t sum = 0;
+    for (uint32_t w = 0; w < nblocks; ++w) sum += slab32[(size_t)w * 768u + bin];
+    out32[bin] = sum;
+}
+
+// out64[bin] = sum over workgroups of slab64[wg][bin]; the slab is zeroed for the next batch.
+__global__ void rd_reduce_slab64(unsigned long long *__restrict__ slab64, uint32_t nblocks,
+                                 unsigned long long *__restrict__ out64)
+{
+    const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= 768u) return;
+    unsigned long long sum = 0;
+    for (uint32_t w = 0; w < nblocks; ++w) {
+        sum += slab64[(size_t)w * 768u + bin];
+        slab64[(size_t)w * 768u + bin] = 0ull;
+    }
+    out64[bin] = sum;
+}

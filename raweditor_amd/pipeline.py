@@ -1,0 +1,140 @@
+"""RenderPipeline -- host mirror of `gpu::RenderPipeline` (reference src/gpu/pipeline.rs:81-100,
+:112-737) over the librawdev C ABI.  Same method names, argument meaning and error behaviour:
+`new` raises RawdevError where the reference returns Err(String); renders return tightly packed
+RGBA8 bytes (1-D uint8 arrays, the analogue of Vec<u8>).  All pixel work happens in HIP kernels
+on the MI355X; nothing here computes pixels on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import FMT_RGBA_F16, FMT_RGBA_F32, FMT_RGBA_U8, BYTES_PER_PIXEL, RawdevError, check
+from .edit import EditParams
+
+IDENTITY_MATRIX = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+
+
+def calculate_cam_to_srgb_matrix(xyz_to_cam: Sequence[float]) -> Tuple[float, ...]:
+    """color::calculate_cam_to_srgb_matrix (reference src/color.rs:35-47): the reference returns the
+    identity for ANY input (the real maths is commented out), and so does this mirror."""
+    if len(xyz_to_cam) != 9:
+        raise ValueError("xyz_to_cam must have 9 elements")
+    return IDENTITY_MATRIX
+
+
+def derived_dims(width: int, height: int) -> Tuple[int, int, int, int]:
+    """(preview_w, preview_h, hist_w, hist_h) with pipeline.rs:125-133's truncating f32 arithmetic."""
+    v = [C.c_uint32() for _ in range(4)]
+    check(_lib.lib().rd_derived_dims(width, height, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+class RenderPipeline:
+    """Owns one CFA plane in HBM plus the current uniforms (EditParams, wb, matrix, zoom/pan)."""
+
+    def __init__(self):
+        raise TypeError("use RenderPipeline.new(...)")
+
+    @classmethod
+    def new(cls, image_id: int, raw_data, width: int, height: int, params: EditParams,
+            wb_multipliers: Sequence[float], color_matrix: Sequence[float], device: int = 0) -> "RenderPipeline":
+        """pipeline.rs:114-363.  raw_data: width*height u16, row-major, one sample per photosite."""
+        raw = np.ascontiguousarray(raw_data, dtype=np.uint16).reshape(-1)
+        if raw.size != int(width) * int(height):
+            raise RawdevError(-1, f"raw_data has {raw.size} samples, expected {width}x{height}")
+        if len(wb_multipliers) != 4 or len(color_matrix) != 9:
+            raise RawdevError(-1, "wb_multipliers must have 4 and color_matrix 9 elements")
+        self = object.__new__(cls)
+        self._h = C.c_void_p()
+        self._device = device
+        wb = (C.c_float * 4)(*[float(x) for x in wb_multipliers])
+        cm = (C.c_float * 9)(*[float(x) for x in color_matrix])
+        cp = params.to_c()
+        check(_lib.lib().rd_pipeline_create(device, int(image_id), raw.ctypes.data_as(C.c_void_p), int(width),
+                                            int(height), C.byref(cp), wb, cm, C.byref(self._h)))
+        info = _lib.RdInfo()
+        check(_lib.lib().rd_pipeline_info(self._h, C.byref(info)))
+        # the reference's pub fields (pipeline.rs:89-96)
+        self.width, self.height = info.width, info.height
+        self.preview_width, self.preview_height = info.preview_width, info.preview_height
+        self.histogram_width, self.histogram_height = info.histogram_width, info.histogram_height
+        self.image_id = info.image_id
+        return self
+
+    # -- uniforms ---------------------------------------------------------------------------------
+    def update_uniforms(self, params: EditParams) -> None:                       # pipeline.rs:367-369
+        cp = params.to_c()
+        check(_lib.lib().rd_update_uniforms(self._h, C.byref(cp)))
+
+    def update_uniforms_with_zoom(self, params: EditParams, zoom: float, pan_x: float, pan_y: float) -> None:
+        cp = params.to_c()                                                        # pipeline.rs:373-398
+        check(_lib.lib().rd_update_uniforms_with_zoom(self._h, C.byref(cp), float(zoom), float(pan_x), float(pan_y)))
+
+    def set_black_level(self, black_level: int) -> None:
+        check(_lib.lib().rd_pipeline_set_black_level(self._h, int(black_level)))
+
+    # -- renders ----------------------------------------------------------------------------------
+    def _bytes(self, fn, w: int, h: int) -> np.ndarray:
+        out = np.empty(w * h * 4, np.uint8)
+        check(fn(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def render_to_bytes(self) -> np.ndarray:                                      # pipeline.rs:442-522
+        return self._bytes(_lib.lib().rd_render_to_bytes, self.preview_width, self.preview_height)
+
+    def render_full_res_to_bytes(self) -> np.ndarray:                             # pipeline.rs:526-606
+        return self._bytes(_lib.lib().rd_render_full_res_to_bytes, self.width, self.height)
+
+    def render_to_histogram_bytes(self) -> np.ndarray:                            # pipeline.rs:615-716
+        return self._bytes(_lib.lib().rd_render_to_histogram_bytes, self.histogram_width, self.histogram_height)
+
+    def calculate_histogram(self, rgba_bytes) -> np.ndarray:                      # pipeline.rs:720-736
+        """[[u32;256];3] as a (3,256) uint32 array; trailing bytes that do not fill a pixel are
+        ignored like chunks_exact(4)."""
+        buf = np.ascontiguousarray(rgba_bytes, dtype=np.uint8).reshape(-1)
+        n = buf.size - buf.size % 4
+        hist = np.zeros(768, np.uint32)
+        check(_lib.lib().rd_calculate_histogram(self._h, buf.ctypes.data_as(C.c_void_p), n,
+                                                hist.ctypes.data_as(C.c_void_p)))
+        return hist.reshape(3, 256)
+
+    def dimensions(self) -> Tuple[int, int]:                                      # pipeline.rs:609-611
+        return (self.width, self.height)
+
+    # -- extensions beyond the reference surface -----------------------------------------------------
+    def render(self, out_w: Optional[int] = None, out_h: Optional[int] = None, fmt: int = FMT_RGBA_F32,
+               with_histogram: bool = False):
+        """Any target size / surface format with the current uniforms.  Returns the surface as an
+        (h, w, 4) array (float32 / float16 / uint8) and, if requested, the fused (3,256) histogram."""
+        w = self.width if out_w is None else int(out_w)
+        h = self.height if out_h is None else int(out_h)
+        dt = {FMT_RGBA_F32: np.float32, FMT_RGBA_F16: np.float16, FMT_RGBA_U8: np.uint8}[fmt]
+        out = np.empty((h, w, 4), dt)
+        hist = np.zeros(768, np.uint32) if with_histogram else None
+        check(_lib.lib().rd_render(self._h, w, h, fmt, out.ctypes.data_as(C.c_void_p), out.nbytes,
+                                   hist.ctypes.data_as(C.c_void_p) if with_histogram else None))
+        return (out, hist.reshape(3, 256)) if with_histogram else out
+
+    def render_device(self, out_w: int, out_h: int, fmt: int, dst_dev: int, hist_dev: int = 0, stream: int = 0) -> None:
+        """Enqueue on `stream` (a hipStream_t as int) into device memory; not synchronised."""
+        check(_lib.lib().rd_render_device(self._h, int(out_w), int(out_h), fmt, C.c_void_p(dst_dev),
+                                          C.c_void_p(hist_dev) if hist_dev else None,
+                                          C.c_void_p(stream) if stream else None))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().rd_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self):                                                           # pipeline.rs:103-110
+        return f"RenderPipeline {{ width: {self.width}, height: {self.height}, .. }}"

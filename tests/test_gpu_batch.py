@@ -1,0 +1,90 @@
+"""-m gpu: the batch export entry points (rd_batch_*): device-resident frames, one fused launch per
+frame (or per row band), u64 histogram accumulation across frames."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import DevBuf, sync
+from tests.helpers import CM_TEST, WB_DAYLIGHT, random_cfa, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_batch(ra, refc, h, w, n, fmt, bands, with_hist=True):
+    rng = np.random.default_rng([0x52415745, h, w, n])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+    bpp = ra.BYTES_PER_PIXEL[fmt]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    d_out = [DevBuf(h * w * bpp) for _ in range(n)]
+    d_hist = DevBuf(768 * 8)
+    be = ra.BatchExporter(0, w, h, fmt, with_hist)
+    frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
+    exp_hist = np.zeros(768, np.uint64)
+    exps = []
+    for c, p in zip(cfas, params):
+        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+        e = refc.render_f32(c, u)
+        exps.append(e)
+        exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
+    for rep in range(2):                       # second pass: the accumulator was reset by histogram()
+        be.develop(frames, row_bands=bands)
+        if with_hist:
+            be.histogram(d_hist.ptr)
+        sync()
+        for e, o in zip(exps, d_out):
+            if fmt == ra.FMT_RGBA_F32:
+                got = o.to_array(np.float32, (h, w, 4))
+                assert np.array_equal(got.view(np.uint32), e.view(np.uint32))
+            elif fmt == ra.FMT_RGBA_F16:
+                got = o.to_array(np.uint16, (h, w, 4))
+                assert np.array_equal(got, refc.pack_f16(e).view(np.uint16))
+            else:
+                got = o.to_array(np.uint8, (h, w, 4))
+                assert np.array_equal(got, refc.pack_u8(e))
+        if with_hist:
+            got_hist = d_hist.to_array(np.uint64, (768,))
+            assert np.array_equal(got_hist, exp_hist)
+    # accumulate over two develop() calls before one histogram(): counts add up in u64
+    if with_hist:
+        be.develop(frames, row_bands=bands)
+        be.develop(frames, row_bands=1)
+        be.histogram(d_hist.ptr)
+        sync()
+        assert np.array_equal(d_hist.to_array(np.uint64, (768,)), 2 * exp_hist)
+    be.close()
+
+
+@pytest.mark.parametrize("fmt_name", ["F32", "F16", "U8"])
+@pytest.mark.parametrize("bands", [1, 3])
+def test_batch_small_frames(gpu_lib, refc, fmt_name, bands):
+    ra = gpu_lib
+    fmt = {"F32": ra.FMT_RGBA_F32, "F16": ra.FMT_RGBA_F16, "U8": ra.FMT_RGBA_U8}[fmt_name]
+    _run_batch(ra, refc, 34, 48, 5, fmt, bands)
+
+
+def test_batch_odd_height_many_bands_no_hist(gpu_lib, refc):
+    ra = gpu_lib
+    _run_batch(ra, refc, 33, 64, 3, ra.FMT_RGBA_F32, 8, with_hist=False)
+    _run_batch(ra, refc, 2, 2, 2, ra.FMT_RGBA_F32, 4)          # more bands than units
+
+
+def test_batch_mid_size_frames(gpu_lib, refc):
+    """A frame big enough to occupy every workgroup of the fixed grid (1504 x 1000)."""
+    ra = gpu_lib
+    _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F32, 1)
+    _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F16, 4)
+
+
+def test_batch_rejects_bad_arguments(gpu_lib):
+    ra = gpu_lib
+    with pytest.raises(ra.RawdevError):
+        ra.BatchExporter(0, 7, 8, ra.FMT_RGBA_F32)               # odd width
+    with pytest.raises(ra.RawdevError):
+        ra.BatchExporter(0, 8, 8, 5)                             # unknown format
+    be = ra.BatchExporter(0, 8, 8, ra.FMT_RGBA_F32, with_histogram=False)
+    with pytest.raises(ra.RawdevError):
+        be.histogram(1234)                                       # created without a histogram
+    buf = DevBuf(8 * 8 * 16 + 16)
+    frames = be.make_frames([buf.ptr], [buf.ptr + 4], [ra.EditParams()], WB_DAYLIGHT, CM_TEST)
+    with pytest.raises(ra.RawdevError):
+        be.develop(frames)                                       # misaligned f32 surface

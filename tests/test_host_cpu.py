@@ -1,0 +1,135 @@
+"""CPU: host-side mirror of the reference interface + the C ABI surface (no GPU compute).
+
+The EditParams tests restate the reference's own unit tests (src/state/edit.rs:125-164); the ABI
+tests check that librawdev.so loads and exports every symbol include/rawdev.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raweditor_amd as ra
+from raweditor_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- state/edit.rs:129-163 ------------------------------------------------------------------------------
+def test_default_is_unedited():
+    assert ra.EditParams.default().is_unedited()
+    assert ra.EditParams.new().is_unedited()
+
+
+def test_serialization():
+    p = ra.EditParams()
+    p.exposure = 1.5
+    p.contrast = 25.0
+    p.saturation = -10.0
+    text = p.to_json()
+    assert ra.EditParams.from_json(text) == ra.EditParams(exposure=1.5, contrast=25.0, saturation=-10.0)
+    # serde field order / names (edit.rs:14-77)
+    assert re.findall(r'"(\w+)":', text) == list(ra.FIELDS)
+    assert text.startswith('{"exposure":1.5,"contrast":25.0,')
+
+
+def test_reset():
+    p = ra.EditParams()
+    p.exposure = 2.0
+    p.contrast = 50.0
+    assert not p.is_unedited()
+    p.reset()
+    assert p.is_unedited()
+
+
+def test_defaults_and_f32_storage():
+    p = ra.EditParams()
+    assert [getattr(p, f) for f in ra.FIELDS] == [0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0]       # edit.rs:81-95
+    assert ra.EditParams(blacks=0.1).blacks == float(np.float32(0.1))
+    with pytest.raises(ValueError):
+        ra.EditParams.from_json('{"exposure": 1.0}')                                    # serde: missing field
+    c = ra.EditParams(tint=-0.25).to_c()
+    assert C.sizeof(c) == 40 and c.tint == -0.25 and c.whites == 1.0
+
+
+def test_random_params_in_ui_ranges(rng):
+    for _ in range(50):
+        p = ra.EditParams.random(rng)
+        for f in ra.FIELDS:
+            lo, hi = ra.UI_RANGES[f]
+            assert lo - 1e-6 <= getattr(p, f) <= hi + 1e-6
+
+
+def test_cam_to_srgb_is_identity_stub():
+    # color.rs:35-47 returns identity for any input; color.rs:193-206 checks a non-zero element
+    m = ra.calculate_cam_to_srgb_matrix([0.8, 0.1, 0.1, 0.2, 0.7, 0.1, 0.0, 0.3, 0.9])
+    assert m == ra.IDENTITY_MATRIX
+
+
+# ---- the C ABI ------------------------------------------------------------------------------------------
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rawdev.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared_symbols()
+    assert len(names) >= 25
+    L = _lib.lib()
+    for n in names:
+        assert hasattr(L, n), f"librawdev.so does not export {n}"
+    assert sorted(_lib.PROTOTYPES) == names, "python prototypes out of sync with include/rawdev.h"
+    assert L.rd_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.RdEditParams) == 40
+    assert C.sizeof(_lib.RdInfo) == 32
+    assert C.sizeof(_lib.RdFrame) == 8 + 8 + 40 + 16 + 36 + 4 + 0 or C.sizeof(_lib.RdFrame) % 8 == 0
+    assert _lib.lib().rd_format_bytes_per_pixel(ra.FMT_RGBA_F32) == 16
+    assert _lib.lib().rd_format_bytes_per_pixel(ra.FMT_RGBA_F16) == 8
+    assert _lib.lib().rd_format_bytes_per_pixel(ra.FMT_RGBA_U8) == 4
+    assert _lib.lib().rd_format_bytes_per_pixel(7) == 0
+
+
+def test_derived_dims_match_reference_formula(refc):
+    for w, h in [(6016, 4016), (11648, 8736), (4000, 6000), (640, 480), (1280, 854), (100, 1000), (3, 2)]:
+        assert ra.derived_dims(w, h) == refc.derived_dims(w, h)
+    assert ra.derived_dims(6016, 4016) == (1280, 854, 128, 85)                          # pipeline.rs:125-133
+
+
+def test_default_params_from_c():
+    p = _lib.RdEditParams()
+    _lib.lib().rd_edit_params_default(C.byref(p))
+    assert [getattr(p, f) for f in ra.FIELDS] == [0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0]
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    L = _lib.lib()
+    assert L.rd_pipeline_info(None, None) == -1
+    assert b"NULL" in L.rd_last_error()
+    assert L.rd_update_uniforms(None, None) == -1
+    out = C.c_void_p()
+    assert L.rd_batch_create(0, 0, 10, 0, 1, C.byref(out)) == -1          # empty frame
+    assert L.rd_batch_create(0, 7, 10, 0, 1, C.byref(out)) == -5          # odd width unsupported in batch
+    L.rd_pipeline_destroy(None)                                             # NULL is a no-op
+    L.rd_batch_destroy(None)
+    with pytest.raises(ra.RawdevError):
+        ra.RenderPipeline.new(1, np.zeros(15, np.uint16), 4, 4, ra.EditParams(), (1, 1, 1, 1), ra.IDENTITY_MATRIX)
+
+
+@pytest.mark.skipif(ra.device_count() > 0, reason="a GPU is present")
+def test_no_device_fails_loudly():
+    """No CPU fallback: without a device, construction is an error (the reference's Err(String))."""
+    with pytest.raises(ra.RawdevError) as e:
+        ra.RenderPipeline.new(1, np.zeros(16, np.uint16), 4, 4, ra.EditParams(), (1, 1, 1, 1), ra.IDENTITY_MATRIX)
+    assert e.value.code in (-2, -3)
+
+
+def test_shard_frames():
+    assert ra.shard_frames(10, 0, 4) == [0, 4, 8] and ra.shard_frames(10, 3, 4) == [3, 7]
+    allf = sorted(sum((ra.shard_frames(2048, r, 8) for r in range(8)), []))
+    assert allf == list(range(2048)) and all(len(ra.shard_frames(2048, r, 8)) == 256 for r in range(8))
+    with pytest.raises(ValueError):
+        ra.shard_frames(4, 4, 4)
