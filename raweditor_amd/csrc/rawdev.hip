@@ -147,10 +147,10 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
                               uint32_t unit1, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
                               unsigned long long *slab64, hipStream_t s)
 {
-    const uint32_t qpr = W >> 1;
-    const uint32_t stride = blocks * RD_BLOCK;
+    const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
+    const uint32_t nwaves = blocks * RD_WAVES;
     hipLaunchKernelGGL((rd_develop_quads<FMT, HIST>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                       unit0, unit1, stride / qpr, stride % qpr, u, slab32, slab64);
+                       unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
 }
 
 template <int FMT, bool HIST>
@@ -184,7 +184,7 @@ static uint32_t rd_blocks_for(const rd_launch_cfg &cfg, uint64_t items, bool his
     return b ? (uint32_t)b : 1u;
 }
 
-static size_t rd_align_for(uint32_t fmt) { return fmt == RD_FMT_RGBA_F32 ? 16 : fmt == RD_FMT_RGBA_F16 ? 8 : 4; }
+static size_t rd_align_for(uint32_t) { return 16; }   // every surface is written with 8- or 16-byte vectors
 
 // Enqueue one render of (cfa, W, H) to a tw x th target.  Returns the number of workgroups used
 // (the slab rows written) through *blocks_out.  use_quads selects the export kernel.
@@ -196,7 +196,7 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
 {
     uint32_t blocks;
     if (use_quads) {
-        const uint64_t items = (uint64_t)(unit1 - unit0) * (W >> 1);
+        const uint64_t items = (uint64_t)(unit1 - unit0) * (((W >> 1) + 63u) / 64u) * 64u;   // lanes
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
         RD_DISPATCH(rd_launch_quads_t, fmt, hist, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, s);
@@ -466,7 +466,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
     if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    const uint64_t items = (uint64_t)(h / 2u + 1u) * (w >> 1);
+    const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
     if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
     int n_cu = 0;
     int rc = rd_check_device(device, &n_cu);

@@ -42,6 +42,23 @@ __device__ __forceinline__ float rd_dot709(float r, float g, float b)
     return ((r * 0.2126f) + (g * 0.7152f)) + (b * 0.0722f);
 }
 
+// a / u.den, correctly rounded (shaders.rs:239).  The denominator is uniform, so its correctly
+// rounded reciprocal u.rden comes from the host; two residual corrections (Markstein: y = RN(1/d),
+// q faithful  =>  RN(q + (a - d*q)*y) = RN(a/d)) give the IEEE quotient in 5 FMAs instead of the
+// ~14-instruction generic v_div_scale/v_rcp/v_div_fmas expansion; v_div_fixup_f32 restores the
+// IEEE special cases (a = 0/inf/NaN, d = 0).  u.fast_div is cleared by the host when d or 1/d is
+// not a normal finite number; the generic divide runs then.  tools/div_check.c: 10^9 samples equal.
+__device__ __forceinline__ float rd_div_den(const rd_ku &u, float a)
+{
+    if (!u.fast_div) return a / u.den;
+    float q = a * u.rden;
+    float e = __builtin_fmaf(-u.den, q, a);
+    q = __builtin_fmaf(e, u.rden, q);
+    e = __builtin_fmaf(-u.den, q, a);
+    q = __builtin_fmaf(e, u.rden, q);
+    return __builtin_amdgcn_div_fixupf(q, u.den, a);
+}
+
 __device__ __forceinline__ rd_rgb rd_colour(const rd_ku &u, float r, float g, float b)
 {
     r = r * u.wb_r; g = g * u.wb_g; b = b * u.wb_b;                    // :195
@@ -58,9 +75,9 @@ __device__ __forceinline__ rd_rgb rd_colour(const rd_ku &u, float r, float g, fl
     r = (r - 0.5f) * u.cf + 0.5f;                                      // :233-234
     g = (g - 0.5f) * u.cf + 0.5f;
     b = (b - 0.5f) * u.cf + 0.5f;
-    r = (r - u.blacks) / u.den;                                        // :239
-    g = (g - u.blacks) / u.den;
-    b = (b - u.blacks) / u.den;
+    r = rd_div_den(u, r - u.blacks);                                   // :239
+    g = rd_div_den(u, g - u.blacks);
+    b = rd_div_den(u, b - u.blacks);
     float Y = rd_dot709(r, g, b);                                      // :243
     float ys = Y * u.oms;                                              // mix(Y, c, s) :247
     r = ys + r * u.s; g = ys + g * u.s; b = ys + b * u.s;
@@ -145,84 +162,139 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // rd_develop_quads -- the export hot path.
 //
 // Work unit u (0 <= u <= H/2) = CFA/output rows a = 2u-1 and b = 2u (a = -1 and b = H do not
-// exist and are skipped); item = (unit, q) owns columns 2q, 2q+1.  With A,B = cfa[a][2q..2q+1]
+// exist and are skipped); a lane owns columns 2q, 2q+1 of one unit.  With A,B = cfa[a][2q..2q+1]
 // and C,D = cfa[b][2q..2q+1] (row indices clamped to the image, which reproduces get_neighbor's
 // edge clamp for the first and last row) the selection table of shaders.rs:127-155 gives
 //     row a (py odd),  both columns : (r,g,b) = (C, A, B)
 //     row b (py even), column 2q    : (r,g,b) = (C, D, A)     <- blue taken from a green site
 //     row b (py even), column 2q+1  : (r,g,b) = (C, D, B)
 // Requires W even and cfa 4-byte aligned (the host falls back to rd_develop_map otherwise).
-// Items are dealt grid-stride so consecutive lanes read/write consecutive addresses; the (unit,q)
-// pair is advanced incrementally (no per-item division); the next item's two loads are issued
-// before the current item's arithmetic and stores so a load never waits behind a younger store.
+//
+// Scheduling: a WAVE owns a tile = 64 consecutive quads of one unit (128 px x 2 rows); tiles are
+// dealt round-robin to the resident waves.  Tile bookkeeping (unit, tile-in-unit, row bases) is
+// wave-uniform and lives in SGPRs/SALU; per-lane integer work is one lane offset.  The next
+// tile's two loads (256 B per row per wave) are issued before the current tile's arithmetic and
+// stores, so a load never waits behind a younger store in the in-order vmcnt queue.
+//
+// Stores: a lane's two f32 pixels are 32 B, so storing them directly gives every store
+// instruction a 32-B lane stride (half-used 64-B requests; measured 2.4 TB/s when store-bound).
+// The f32 surface therefore goes through a wave-private LDS transpose (3 ds_write_b128 +
+// 4 ds_read_b128 per lane) so that every global_store_dwordx4 writes 1 KiB contiguous.  f16
+// (16 B per lane per row) and u8 (8 B) are contiguous as they are and skip the transpose.
 // ---------------------------------------------------------------------------------------------
+#define RD_WAVES (RD_BLOCK / 64)
+
 template <int FMT, bool HIST>
 __global__ void __launch_bounds__(RD_BLOCK)
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
-                 uint32_t unit0, uint32_t unit1, uint32_t stride_units, uint32_t stride_rem,
-                 rd_ku u, uint32_t *slab32, unsigned long long *slab64)
+                 uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t step_units,
+                 uint32_t step_rem, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
 {
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
+    __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     if (HIST) rd_hist_zero(lh);
 
-    const uint32_t qpr = W >> 1;                       // items per unit
-    const uint32_t total = (unit1 - unit0) * qpr;      // < 2^32: checked on the host
-    const uint32_t copy = threadIdx.x & (RD_HK - 1);
-    uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t stride = gridDim.x * blockDim.x;    // == stride_units*qpr + stride_rem
-    uint32_t unit = unit0 + item / qpr;
-    uint32_t q = item % qpr;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qpr = W >> 1;                                 // quads per unit
+    const uint32_t ntiles = (unit1 - unit0) * tpu;               // < 2^32: checked on the host
+    const uint32_t nwaves = gridDim.x * RD_WAVES;                // == step_units*tpu + step_rem
+    const uint32_t copy = lane & (RD_HK - 1);
+    uint32_t tile = blockIdx.x * RD_WAVES + wave;
+    uint32_t unit = unit0 + tile / tpu;
+    uint32_t qt = tile % tpu;
 
     uint32_t top = 0, bot = 0;
-    if (item < total) {
-        uint32_t ra = unit ? 2u * unit - 1u : 0u;
-        uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
-        top = *reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W + 2u * q);
-        bot = *reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W + 2u * q);
-    }
-    while (item < total) {
-        // ---- prefetch the next item ----
-        uint32_t nitem = item + stride;
-        uint32_t nunit = unit + stride_units, nq = q + stride_rem;
-        if (nq >= qpr) { nq -= qpr; nunit += 1u; }
-        uint32_t ntop = 0, nbot = 0;
-        if (nitem < total) {
-            uint32_t ra = nunit ? 2u * nunit - 1u : 0u;
-            uint32_t rb = 2u * nunit < H ? 2u * nunit : H - 1u;
-            ntop = *reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W + 2u * nq);
-            nbot = *reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W + 2u * nq);
+    if (tile < ntiles) {
+        const uint32_t q = qt * 64u + lane;
+        const uint32_t ra = unit ? 2u * unit - 1u : 0u;
+        const uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
+        if (q < qpr) {
+            top = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W)[q];
+            bot = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W)[q];
         }
-        // ---- this item ----
-        const bool has_a = unit != 0u;
-        const bool has_b = 2u * unit < H;
+    }
+    while (tile < ntiles) {
+        // ---- prefetch the next tile (wave-uniform bookkeeping) ----
+        const uint32_t ntile = tile + nwaves;
+        uint32_t nunit = unit + step_units, nqt = qt + step_rem;
+        if (nqt >= tpu) { nqt -= tpu; nunit += 1u; }
+        uint32_t ntop = 0, nbot = 0;
+        if (ntile < ntiles) {
+            const uint32_t q = nqt * 64u + lane;
+            const uint32_t ra = nunit ? 2u * nunit - 1u : 0u;
+            const uint32_t rb = 2u * nunit < H ? 2u * nunit : H - 1u;
+            if (q < qpr) {
+                ntop = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W)[q];
+                nbot = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W)[q];
+            }
+        }
+        // ---- this tile ----
+        const bool has_a = unit != 0u;            // wave-uniform
+        const bool has_b = 2u * unit < H;         // wave-uniform
+        const uint32_t q = qt * 64u + lane;
+        const bool valid = q < qpr;
         const float A = rd_norm(top & 0xffffu, u.black_level), B = rd_norm(top >> 16, u.black_level);
         const float C = rd_norm(bot & 0xffffu, u.black_level), D = rd_norm(bot >> 16, u.black_level);
-        if (has_a) {
-            const rd_rgb c1 = rd_colour(u, C, A, B);
-            uint32_t qr = 0, qg = 0, qb = 0;
-            if (HIST || FMT == RD_FMT_RGBA_U8) { qr = rd_q8(c1.r); qg = rd_q8(c1.g); qb = rd_q8(c1.b); }
-            const size_t px = (size_t)(2u * unit - 1u) * W + 2u * q;
-            rd_store_px<FMT>(out, px, c1, qr, qg, qb);
-            rd_store_px<FMT>(out, px + 1, c1, qr, qg, qb);
-            if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 2u);
+        const rd_rgb c1 = rd_colour(u, C, A, B);
+        const rd_rgb c2 = rd_colour(u, C, D, A);
+        const rd_rgb c3 = rd_colour(u, C, D, B);
+        uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
+        if (HIST || FMT == RD_FMT_RGBA_U8) {
+            q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
+            q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
+            q3r = rd_q8(c3.r); q3g = rd_q8(c3.g); q3b = rd_q8(c3.b);
         }
-        if (has_b) {
-            const rd_rgb c2 = rd_colour(u, C, D, A);
-            const rd_rgb c3 = rd_colour(u, C, D, B);
-            uint32_t qr2 = 0, qg2 = 0, qb2 = 0, qr3 = 0, qg3 = 0, qb3 = 0;
-            if (HIST || FMT == RD_FMT_RGBA_U8) {
-                qr2 = rd_q8(c2.r); qg2 = rd_q8(c2.g); qb2 = rd_q8(c2.b);
-                qr3 = rd_q8(c3.r); qg3 = rd_q8(c3.g); qb3 = rd_q8(c3.b);
+        if (HIST && valid) {
+            if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
+            if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
+        }
+        const size_t row_a = (size_t)(2u * unit - 1u) * W;   // pixel index of the row start (unused if !has_a)
+        const size_t row_b = (size_t)(2u * unit) * W;
+        if (FMT == RD_FMT_RGBA_F32) {
+            rd_f4 *st = stage + (size_t)wave * 192u;         // wave-private: [lane][c1,c2,c3]
+            st[lane * 3u + 0u] = rd_f4{ c1.r, c1.g, c1.b, 1.0f };
+            st[lane * 3u + 1u] = rd_f4{ c2.r, c2.g, c2.b, 1.0f };
+            st[lane * 3u + 2u] = rd_f4{ c3.r, c3.g, c3.b, 1.0f };
+            __builtin_amdgcn_wave_barrier();
+            rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
+#pragma unroll
+            for (uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t p = half * 64u + lane;                  // pixel within the tile
+                const uint32_t px = qt * 128u + p;                     // column
+                const rd_f4 va = st[(p >> 1) * 3u];                    // row a: c1 of quad p/2
+                const rd_f4 vb = st[(p >> 1) * 3u + 1u + (p & 1u)];    // row b: c2 (even col) / c3 (odd col)
+                if (px < W) {
+                    if (has_a) __builtin_nontemporal_store(va, o + row_a + px);
+                    if (has_b) __builtin_nontemporal_store(vb, o + row_b + px);
+                }
             }
-            const size_t px = (size_t)(2u * unit) * W + 2u * q;
-            rd_store_px<FMT>(out, px, c2, qr2, qg2, qb2);
-            rd_store_px<FMT>(out, px + 1, c3, qr3, qg3, qb3);
-            if (HIST) {
-                rd_hist_add(lh, copy, qr2, qg2, qb2, 1u);
-                rd_hist_add(lh, copy, qr3, qg3, qb3, 1u);
+            __builtin_amdgcn_wave_barrier();
+        } else if (FMT == RD_FMT_RGBA_F16) {
+            typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
+            rd_u4 *o = reinterpret_cast<rd_u4 *>(out);                 // 2 px = 16 B
+            if (valid) {
+                const rd_h2 one = { (_Float16)0.0f, (_Float16)1.0f };
+                rd_h2 a_rg = { (_Float16)c1.r, (_Float16)c1.g }, a_b1 = { (_Float16)c1.b, one.y };
+                rd_h2 b_rg = { (_Float16)c2.r, (_Float16)c2.g }, b_b1 = { (_Float16)c2.b, one.y };
+                rd_h2 c_rg = { (_Float16)c3.r, (_Float16)c3.g }, c_b1 = { (_Float16)c3.b, one.y };
+                const uint32_t a0 = __builtin_bit_cast(uint32_t, a_rg), a1 = __builtin_bit_cast(uint32_t, a_b1);
+                if (has_a) __builtin_nontemporal_store(rd_u4{ a0, a1, a0, a1 }, o + (row_a >> 1) + q);
+                if (has_b) __builtin_nontemporal_store(rd_u4{ __builtin_bit_cast(uint32_t, b_rg), __builtin_bit_cast(uint32_t, b_b1),
+                                                              __builtin_bit_cast(uint32_t, c_rg), __builtin_bit_cast(uint32_t, c_b1) },
+                                                       o + (row_b >> 1) + q);
+            }
+        } else {
+            rd_u2 *o = reinterpret_cast<rd_u2 *>(out);                 // 2 px = 8 B
+            if (valid) {
+                const uint32_t v1 = q1r | (q1g << 8) | (q1b << 16) | 0xff000000u;
+                const uint32_t v2 = q2r | (q2g << 8) | (q2b << 16) | 0xff000000u;
+                const uint32_t v3 = q3r | (q3g << 8) | (q3b << 16) | 0xff000000u;
+                if (has_a) __builtin_nontemporal_store(rd_u2{ v1, v1 }, o + (row_a >> 1) + q);
+                if (has_b) __builtin_nontemporal_store(rd_u2{ v2, v3 }, o + (row_b >> 1) + q);
             }
         }
-        item = nitem; unit = nunit; q = nq; top = ntop; bot = nbot;
+        tile = ntile; unit = nunit; qt = nqt; top = ntop; bot = nbot;
     }
     if (HIST) rd_hist_flush(lh, slab32, slab64);
 }

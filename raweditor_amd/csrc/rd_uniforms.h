@@ -18,6 +18,8 @@ struct rd_ku {
     float highlights, shadows;   // :226, :230
     float cf;                    // 1 + contrast/100 (:233)
     float blacks, den;           // :239  den = (whites-blacks)+0.0001
+    float rden;                  // RN(1/den), for the correctly rounded reciprocal division
+    uint32_t fast_div;           // den and 1/den are normal finite numbers
     float s, oms;                // 1 + saturation/100 and 1-s (:245-247)
     float vibrance;              // :254
     float zoom, pan_x, pan_y;    // :46-51
@@ -40,6 +42,11 @@ static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const
     u.cf = 1.0f + (p.contrast / 100.0f);
     u.blacks = p.blacks;
     u.den = (p.whites - p.blacks) + 0.0001f;
+    u.rden = 1.0f / u.den;
+    {
+        const float ad = __builtin_fabsf(u.den), ay = __builtin_fabsf(u.rden);
+        u.fast_div = (ad >= RD_FLT_MIN && ad <= 3.0e38f && ay >= RD_FLT_MIN && ay <= 3.0e38f) ? 1u : 0u;
+    }
     u.s = 1.0f + (p.saturation / 100.0f);
     u.oms = 1.0f - u.s;
     u.vibrance = p.vibrance;
