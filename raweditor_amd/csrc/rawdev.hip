@@ -149,8 +149,12 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
 {
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
     const uint32_t nwaves = blocks * RD_WAVES;
-    hipLaunchKernelGGL((rd_develop_quads<FMT, HIST>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                       unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+    if (W % 128u == 0)
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+                           unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+    else
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+                           unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
 }
 
 template <int FMT, bool HIST>

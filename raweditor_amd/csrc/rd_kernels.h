@@ -183,13 +183,35 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // (16 B per lane per row) and u8 (8 B) are contiguous as they are and skip the transpose.
 // ---------------------------------------------------------------------------------------------
 #define RD_WAVES (RD_BLOCK / 64)
+#ifdef RD_COLOUR_HOOK_HEADER  // tools/microbench.hip only: swaps in reduced-VALU stand-ins to find the memory floor
+#include RD_COLOUR_HOOK_HEADER
+#endif
+#ifndef RD_COLOUR
+#define RD_COLOUR rd_colour
+#endif
 
-template <int FMT, bool HIST>
+// FULL = every tile is a whole 64 quads (W % 128 == 0, true for 6016 and 11648): no lane masks, so
+// every vector-memory instruction of the loop body is issued unconditionally.  That matters: vmcnt
+// retires in issue order, and hipcc can only leave the four stores of tile i in flight while it
+// waits for the prefetched loads of tile i+1 (s_waitcnt vmcnt(4)) if it can COUNT them; one store
+// behind a branch makes it fall back to vmcnt(0), which drains the store queue every iteration
+// (measured: +20 us per frame).  For the same reason the first/last unit (one of the two rows does
+// not exist) is handled by redirecting that row's store onto the other row with the other row's
+// value -- a duplicate store of correct data -- instead of branching around it.
+// One tile's results, packed the way its surface stores want them, carried in registers from the
+// iteration that computes them to the next one, which stores them.
+template <int FMT> struct rd_tile_out;
+template <> struct rd_tile_out<RD_FMT_RGBA_F32> { rd_rgb c1, c2, c3; };
+template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
+template <> struct rd_tile_out<RD_FMT_RGBA_U8> { uint32_t v1, v2, v3; };
+
+template <int FMT, bool HIST, bool FULL, bool BURST = false>
 __global__ void __launch_bounds__(RD_BLOCK)
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                  uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t step_units,
                  uint32_t step_rem, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
 {
+    typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     if (HIST) rd_hist_zero(lh);
@@ -204,41 +226,25 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
     uint32_t unit = unit0 + tile / tpu;
     uint32_t qt = tile % tpu;
 
-    uint32_t top = 0, bot = 0;
-    if (tile < ntiles) {
-        const uint32_t q = qt * 64u + lane;
-        const uint32_t ra = unit ? 2u * unit - 1u : 0u;
-        const uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
-        if (q < qpr) {
-            top = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W)[q];
-            bot = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W)[q];
-        }
-    }
-    while (tile < ntiles) {
-        // ---- prefetch the next tile (wave-uniform bookkeeping) ----
-        const uint32_t ntile = tile + nwaves;
-        uint32_t nunit = unit + step_units, nqt = qt + step_rem;
-        if (nqt >= tpu) { nqt -= tpu; nunit += 1u; }
-        uint32_t ntop = 0, nbot = 0;
-        if (ntile < ntiles) {
-            const uint32_t q = nqt * 64u + lane;
-            const uint32_t ra = nunit ? 2u * nunit - 1u : 0u;
-            const uint32_t rb = 2u * nunit < H ? 2u * nunit : H - 1u;
-            if (q < qpr) {
-                ntop = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W)[q];
-                nbot = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W)[q];
-            }
-        }
-        // ---- this tile ----
-        const bool has_a = unit != 0u;            // wave-uniform
-        const bool has_b = 2u * unit < H;         // wave-uniform
-        const uint32_t q = qt * 64u + lane;
-        const bool valid = q < qpr;
+    // cfa[ra][2q..2q+1] and cfa[rb][2q..2q+1] of tile (pu, pq) for this lane; rows clamped to the image.
+    auto load_tile = [&](uint32_t pu, uint32_t pq, uint32_t &top, uint32_t &bot) {
+        uint32_t q = pq * 64u + lane;
+        if (!FULL) q = q < qpr ? q : qpr - 1u;                   // clamp: loaded but never used
+        const uint32_t ra = pu ? 2u * pu - 1u : 0u;
+        const uint32_t rb = 2u * pu < H ? 2u * pu : H - 1u;
+        top = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W)[q];
+        bot = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W)[q];
+    };
+
+    // demosaic + colour stack + histogram of one tile -> packed results
+    auto compute_tile = [&](uint32_t tu, uint32_t tq, uint32_t top, uint32_t bot) {
+        const bool has_a = tu != 0u, has_b = 2u * tu < H;        // wave-uniform
+        const bool valid = FULL || (tq * 64u + lane) < qpr;
         const float A = rd_norm(top & 0xffffu, u.black_level), B = rd_norm(top >> 16, u.black_level);
         const float C = rd_norm(bot & 0xffffu, u.black_level), D = rd_norm(bot >> 16, u.black_level);
-        const rd_rgb c1 = rd_colour(u, C, A, B);
-        const rd_rgb c2 = rd_colour(u, C, D, A);
-        const rd_rgb c3 = rd_colour(u, C, D, B);
+        const rd_rgb c1 = RD_COLOUR(u, C, A, B);
+        const rd_rgb c2 = RD_COLOUR(u, C, D, A);
+        const rd_rgb c3 = RD_COLOUR(u, C, D, B);
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
         if (HIST || FMT == RD_FMT_RGBA_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
@@ -249,52 +255,133 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
             if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
         }
-        const size_t row_a = (size_t)(2u * unit - 1u) * W;   // pixel index of the row start (unused if !has_a)
-        const size_t row_b = (size_t)(2u * unit) * W;
-        if (FMT == RD_FMT_RGBA_F32) {
-            rd_f4 *st = stage + (size_t)wave * 192u;         // wave-private: [lane][c1,c2,c3]
-            st[lane * 3u + 0u] = rd_f4{ c1.r, c1.g, c1.b, 1.0f };
-            st[lane * 3u + 1u] = rd_f4{ c2.r, c2.g, c2.b, 1.0f };
-            st[lane * 3u + 2u] = rd_f4{ c3.r, c3.g, c3.b, 1.0f };
+        rd_tile_out<FMT> r;
+        if constexpr (FMT == RD_FMT_RGBA_F32) {
+            r.c1 = c1; r.c2 = c2; r.c3 = c3;
+        } else if constexpr (FMT == RD_FMT_RGBA_F16) {
+            const rd_h2 a_rg = { (_Float16)c1.r, (_Float16)c1.g }, a_b1 = { (_Float16)c1.b, (_Float16)1.0f };
+            const rd_h2 b_rg = { (_Float16)c2.r, (_Float16)c2.g }, b_b1 = { (_Float16)c2.b, (_Float16)1.0f };
+            const rd_h2 c_rg = { (_Float16)c3.r, (_Float16)c3.g }, c_b1 = { (_Float16)c3.b, (_Float16)1.0f };
+            r.a0 = __builtin_bit_cast(uint32_t, a_rg); r.a1 = __builtin_bit_cast(uint32_t, a_b1);
+            r.b0 = __builtin_bit_cast(uint32_t, b_rg); r.b1 = __builtin_bit_cast(uint32_t, b_b1);
+            r.c0 = __builtin_bit_cast(uint32_t, c_rg); r.c1 = __builtin_bit_cast(uint32_t, c_b1);
+        } else {
+            r.v1 = q1r | (q1g << 8) | (q1b << 16) | 0xff000000u;
+            r.v2 = q2r | (q2g << 8) | (q2b << 16) | 0xff000000u;
+            r.v3 = q3r | (q3g << 8) | (q3b << 16) | 0xff000000u;
+        }
+        return r;
+    };
+
+    // surface stores of one tile.  A missing row (first / last unit) is redirected onto the existing
+    // one with that row's value, so the number of store instructions never depends on the tile.
+    auto store_tile = [&](uint32_t tu, uint32_t tq, const rd_tile_out<FMT> &r) {
+        const bool has_a = tu != 0u, has_b = 2u * tu < H;
+        const size_t row_b_px = (size_t)(has_b ? 2u * tu : 2u * tu - 1u) * W;
+        const size_t row_a_px = has_a ? (size_t)(2u * tu - 1u) * W : row_b_px;
+        const uint32_t q = tq * 64u + lane;
+        const bool valid = FULL || q < qpr;
+        if constexpr (FMT == RD_FMT_RGBA_F32) {
+            rd_f4 *st = stage + (size_t)wave * 192u;             // wave-private: [lane][c1,c2,c3]
+            st[lane * 3u + 0u] = rd_f4{ r.c1.r, r.c1.g, r.c1.b, 1.0f };
+            st[lane * 3u + 1u] = rd_f4{ r.c2.r, r.c2.g, r.c2.b, 1.0f };
+            st[lane * 3u + 2u] = rd_f4{ r.c3.r, r.c3.g, r.c3.b, 1.0f };
             __builtin_amdgcn_wave_barrier();
             rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
 #pragma unroll
             for (uint32_t half = 0; half < 2u; ++half) {
                 const uint32_t p = half * 64u + lane;                  // pixel within the tile
-                const uint32_t px = qt * 128u + p;                     // column
-                const rd_f4 va = st[(p >> 1) * 3u];                    // row a: c1 of quad p/2
-                const rd_f4 vb = st[(p >> 1) * 3u + 1u + (p & 1u)];    // row b: c2 (even col) / c3 (odd col)
-                if (px < W) {
-                    if (has_a) __builtin_nontemporal_store(va, o + row_a + px);
-                    if (has_b) __builtin_nontemporal_store(vb, o + row_b + px);
+                const uint32_t px = tq * 128u + p;                     // column
+                rd_f4 va = st[(p >> 1) * 3u];                          // row a: c1 of quad p/2
+                rd_f4 vb = st[(p >> 1) * 3u + 1u + (p & 1u)];          // row b: c2 (even col) / c3 (odd col)
+                if (!has_a) va = vb;
+                if (!has_b) vb = va;
+                if (FULL || px < W) {
+                    __builtin_nontemporal_store(va, o + row_a_px + px);
+                    __builtin_nontemporal_store(vb, o + row_b_px + px);
                 }
             }
             __builtin_amdgcn_wave_barrier();
-        } else if (FMT == RD_FMT_RGBA_F16) {
-            typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
-            rd_u4 *o = reinterpret_cast<rd_u4 *>(out);                 // 2 px = 16 B
+        } else if constexpr (FMT == RD_FMT_RGBA_F16) {
+            rd_u4 *o = reinterpret_cast<rd_u4 *>(out);                 // 2 px = 16 B per lane per row
+            rd_u4 va = { r.a0, r.a1, r.a0, r.a1 }, vb = { r.b0, r.b1, r.c0, r.c1 };
+            if (!has_a) va = vb;
+            if (!has_b) vb = va;
             if (valid) {
-                const rd_h2 one = { (_Float16)0.0f, (_Float16)1.0f };
-                rd_h2 a_rg = { (_Float16)c1.r, (_Float16)c1.g }, a_b1 = { (_Float16)c1.b, one.y };
-                rd_h2 b_rg = { (_Float16)c2.r, (_Float16)c2.g }, b_b1 = { (_Float16)c2.b, one.y };
-                rd_h2 c_rg = { (_Float16)c3.r, (_Float16)c3.g }, c_b1 = { (_Float16)c3.b, one.y };
-                const uint32_t a0 = __builtin_bit_cast(uint32_t, a_rg), a1 = __builtin_bit_cast(uint32_t, a_b1);
-                if (has_a) __builtin_nontemporal_store(rd_u4{ a0, a1, a0, a1 }, o + (row_a >> 1) + q);
-                if (has_b) __builtin_nontemporal_store(rd_u4{ __builtin_bit_cast(uint32_t, b_rg), __builtin_bit_cast(uint32_t, b_b1),
-                                                              __builtin_bit_cast(uint32_t, c_rg), __builtin_bit_cast(uint32_t, c_b1) },
-                                                       o + (row_b >> 1) + q);
+                __builtin_nontemporal_store(va, o + (row_a_px >> 1) + q);
+                __builtin_nontemporal_store(vb, o + (row_b_px >> 1) + q);
             }
         } else {
-            rd_u2 *o = reinterpret_cast<rd_u2 *>(out);                 // 2 px = 8 B
+            rd_u2 *o = reinterpret_cast<rd_u2 *>(out);                 // 2 px = 8 B per lane per row
+            rd_u2 va = { r.v1, r.v1 }, vb = { r.v2, r.v3 };
+            if (!has_a) va = vb;
+            if (!has_b) vb = va;
             if (valid) {
-                const uint32_t v1 = q1r | (q1g << 8) | (q1b << 16) | 0xff000000u;
-                const uint32_t v2 = q2r | (q2g << 8) | (q2b << 16) | 0xff000000u;
-                const uint32_t v3 = q3r | (q3g << 8) | (q3b << 16) | 0xff000000u;
-                if (has_a) __builtin_nontemporal_store(rd_u2{ v1, v1 }, o + (row_a >> 1) + q);
-                if (has_b) __builtin_nontemporal_store(rd_u2{ v2, v3 }, o + (row_b >> 1) + q);
+                __builtin_nontemporal_store(va, o + (row_a_px >> 1) + q);
+                __builtin_nontemporal_store(vb, o + (row_b_px >> 1) + q);
             }
         }
-        tile = ntile; unit = nunit; qt = nqt; top = ntop; bot = nbot;
+    };
+
+    if (tile < ntiles) {
+        if (BURST) {
+            // ---- phase 0 (OFF by default; kept for A/B): read-only burst.  HBM3E serves this kernel's 1:8 read:write mix badly when
+            // 256-B reads are sprinkled between the write streams: every isolated read costs the DRAM
+            // channel a write->read->write turnaround (measured: the same bytes take 85-88 us mixed but
+            // 65 us when the CFA plane is already in the Infinity Cache).  So every wave first touches
+            // ALL the CFA lines it is going to need, eight loads in flight at a time; the whole chip is
+            // in this phase together (persistent grid, nothing stored yet), the 48 MB land in the 256 MiB
+            // Infinity Cache in one pure-read burst, and the main loop's loads are served on-die.
+            // nt stores do not displace them (measured).
+            uint32_t t = tile, pu = unit, pq = qt, sink = 0;
+            while (t < ntiles) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = t < ntiles;                  // wave-uniform; past the end: re-touch the last tile
+                    load_tile(pu, pq, v[2 * k], v[2 * k + 1]);
+                    if (in) {
+                        t += nwaves;
+                        if (t < ntiles) { pu += step_units; pq += step_rem; if (pq >= tpu) { pq -= tpu; pu += 1u; } }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sink ^= v[k];
+            }
+            asm volatile("" ::"v"(sink));
+        }
+        uint32_t top, bot;
+        load_tile(unit, qt, top, bot);
+        // Land the first tile's loads BEFORE the loop.  hipcc places one static s_waitcnt per use and
+        // merges the loop-entry and back-edge states; with loads still pending at the loop header it
+        // emits vmcnt(1)/vmcnt(2) there, which on the back edge means "drain the stores in flight".
+        asm volatile("" : "+v"(top), "+v"(bot));
+
+        // Software pipeline, one tile deep on each side:
+        //   iteration i:  issue loads(i+1) | store tile i-1 (registers -> LDS transpose -> HBM) | compute tile i
+        // vmcnt retires in order, so waiting for loads(i+1) only requires the stores of tile i-2 to
+        // have completed; the stores of tile i-1 overlap this wave's own arithmetic.
+        uint32_t ntile = tile + nwaves;
+        uint32_t nunit = unit + step_units, nqt = qt + step_rem;
+        if (nqt >= tpu) { nqt -= tpu; nunit += 1u; }
+        bool more = ntile < ntiles;
+        uint32_t ntop, nbot;
+        load_tile(more ? nunit : unit, more ? nqt : qt, ntop, nbot);
+        rd_tile_out<FMT> pend = compute_tile(unit, qt, top, bot);
+        uint32_t punit = unit, pqt = qt;
+        asm volatile("" : "+v"(ntop), "+v"(nbot));               // same reason: nothing pending at the loop header
+        while (more) {
+            tile = ntile; unit = nunit; qt = nqt; top = ntop; bot = nbot;
+            ntile = tile + nwaves;
+            nunit = unit + step_units; nqt = qt + step_rem;
+            if (nqt >= tpu) { nqt -= tpu; nunit += 1u; }
+            more = ntile < ntiles;
+            load_tile(more ? nunit : unit, more ? nqt : qt, ntop, nbot);   // unconditional (last pass re-reads its own)
+            store_tile(punit, pqt, pend);
+            pend = compute_tile(unit, qt, top, bot);
+            punit = unit; pqt = qt;
+        }
+        store_tile(punit, pqt, pend);
     }
     if (HIST) rd_hist_flush(lh, slab32, slab64);
 }

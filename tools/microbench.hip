@@ -9,12 +9,18 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#ifdef MB_LITE
+#define RD_COLOUR_HOOK_HEADER "../../tools/mb_lite.h"
+#endif
 #include "../raweditor_amd/csrc/rd_kernels.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { M_COMPUTE = 1, M_STORE = 2, M_HIST = 4, M_PLAIN_ST = 8, M_LDS_T = 16 };
+enum { M_COMPUTE = 1, M_STORE = 2, M_HIST = 4, M_PLAIN_ST = 8, M_LDS_T = 16, M_FAKE_CONTIG = 32, M_LDS_ONLY = 64, M_LITE = 128, M_LITE2 = 256 };
 
+#ifndef MB_LITE
+#include "mb_lite.h"
+#endif
 // Variant kernel: same loop as rd_develop_quads, pieces switchable.
 template <int MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -22,7 +28,7 @@ mb_quads(const uint16_t *__restrict__ cfa, float *__restrict__ out, uint32_t W, 
          uint32_t stride_units, uint32_t stride_rem, rd_ku u, uint32_t *slab32)
 {
     constexpr bool COMPUTE = MODE & M_COMPUTE, STORE = MODE & M_STORE, HIST = MODE & M_HIST;
-    constexpr bool PLAIN = MODE & M_PLAIN_ST, LDST = MODE & M_LDS_T;
+    constexpr bool PLAIN = MODE & M_PLAIN_ST, LDST = MODE & M_LDS_T, FAKE = MODE & M_FAKE_CONTIG, LDSONLY = MODE & M_LDS_ONLY;
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[LDST ? BLOCK * 3 : 1];     // per lane: c1, c2, c3
     if (HIST) rd_hist_zero(lh);
@@ -56,7 +62,9 @@ mb_quads(const uint16_t *__restrict__ cfa, float *__restrict__ out, uint32_t W, 
         const float A = rd_norm(top & 0xffffu, 0), B = rd_norm(top >> 16, 0);
         const float C = rd_norm(bot & 0xffffu, 0), D = rd_norm(bot >> 16, 0);
         rd_rgb c1, c2, c3;
-        if (COMPUTE) { c1 = rd_colour(u, C, A, B); c2 = rd_colour(u, C, D, A); c3 = rd_colour(u, C, D, B); }
+        if (MODE & M_LITE) { c1 = mb_colour_lite(u, C, A, B, 1); c2 = mb_colour_lite(u, C, D, A, 1); c3 = mb_colour_lite(u, C, D, B, 1); }
+        else if (MODE & M_LITE2) { c1 = mb_colour_lite(u, C, A, B, 0); c2 = mb_colour_lite(u, C, D, A, 0); c3 = mb_colour_lite(u, C, D, B, 0); }
+        else if (COMPUTE) { c1 = rd_colour(u, C, A, B); c2 = rd_colour(u, C, D, A); c3 = rd_colour(u, C, D, B); }
         else { c1 = { C, A, B }; c2 = { C, D, A }; c3 = { C, D, B }; }
         if (HIST) {
             rd_hist_add(lh, copy, rd_q8(c1.r), rd_q8(c1.g), rd_q8(c1.b), 2u);
@@ -78,10 +86,18 @@ mb_quads(const uint16_t *__restrict__ cfa, float *__restrict__ out, uint32_t W, 
                 // row a: pixel p (0..127) = c1 of quad p/2 ; row b: pixel p = (p&1 ? c3 : c2) of quad p/2
                 for (uint32_t half = 0; half < 2; ++half) {
                     const uint32_t p = half * 64u + lane;
+                    if (LDSONLY) { rd_f4 a = stage[wbase + (p >> 1) * 3u + 0], b = stage[wbase + (p >> 1) * 3u + 1u + (p & 1u)]; sink += a.x + b.y; }
+                    else {
                     if (has_a) st(rowa + p, stage[wbase + (p >> 1) * 3u + 0]);
                     if (has_b) st(rowb + p, stage[wbase + (p >> 1) * 3u + 1u + (p & 1u)]);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
+            } else if (FAKE) {
+                const uint32_t lane = threadIdx.x & 63u; const uint32_t q0 = q - lane;
+                const size_t rowa = (size_t)(2u * unit - 1u) * W + 2u * q0, rowb = (size_t)(2u * unit) * W + 2u * q0;
+                if (has_a) { st(rowa + lane, rd_f4{ c1.r, c1.g, c1.b, 1.0f }); st(rowa + 64 + lane, rd_f4{ c1.r, c1.g, c1.b, 1.0f }); }
+                if (has_b) { st(rowb + lane, rd_f4{ c2.r, c2.g, c2.b, 1.0f }); st(rowb + 64 + lane, rd_f4{ c3.r, c3.g, c3.b, 1.0f }); }
             } else {
                 if (has_a) {
                     const size_t px = (size_t)(2u * unit - 1u) * W + 2u * q;
@@ -112,6 +128,76 @@ __global__ void __launch_bounds__(1024) mb_fill(float *__restrict__ out, size_t 
 }
 
 #include <functional>
+// store-pattern probe: every wave writes `ROWS` rows x (4 KiB / ROWS) contiguous bytes per tile, like the
+// export kernel's tile (ROWS = 2) or a one-row tile (ROWS = 1); optional u16 input loads; nt or plain.
+template <int ROWS, bool NT, bool LOADS>
+__global__ void __launch_bounds__(1024) mb_store_pat(const uint16_t *__restrict__ cfa, float *__restrict__ out, uint32_t W, uint32_t H)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 16u + (threadIdx.x >> 6), nwaves = gridDim.x * 16u;
+    const uint32_t px_per_tile = 256u / ROWS;                     // pixels per row per tile
+    const uint32_t tpr = W / px_per_tile;                         // tiles per row(-pair)
+    const uint32_t ntiles = (H / ROWS) * tpr;
+    rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
+    for (uint32_t t = wave; t < ntiles; t += nwaves) {
+        const uint32_t rp = t / tpr, c0 = (t % tpr) * px_per_tile;
+        float v = 0.5f;
+        if (LOADS) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(cfa + (size_t)(rp * ROWS) * W + c0 * (ROWS == 2 ? 1 : 1));
+            v = (float)(src[lane] & 0xfffu) * (1.0f / 4096.0f);
+            if (ROWS == 2) v += (float)(reinterpret_cast<const uint32_t *>(cfa + (size_t)(rp * 2 + 1) * W + c0)[lane] >> 16) * (1.0f / 4096.0f);
+            else v += (float)(src[lane + 64] >> 16) * (1.0f / 4096.0f);
+        }
+        const rd_f4 val = { v, v, v, 1.0f };
+#pragma unroll
+        for (uint32_t r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (uint32_t k = 0; k < 4u / ROWS; ++k) {
+                rd_f4 *dst = o + (size_t)(rp * ROWS + r) * W + c0 + k * 64u + lane;
+                if (NT) __builtin_nontemporal_store(val, dst); else *dst = val;
+            }
+    }
+}
+
+// read:write = 1:8 streaming mix in its simplest form: a wave reads LW*64 contiguous bytes and writes 8x as
+// many contiguous bytes.  Tells whether ~4.9 TB/s is a property of the traffic mix or of the kernel's pattern.
+template <int LW, bool PREFETCH>
+__global__ void __launch_bounds__(1024) mb_mix(const uint32_t *__restrict__ in, float *__restrict__ out, size_t in_dwords)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t wave = (size_t)blockIdx.x * 16u + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 16u;
+    const size_t chunk_dw = (size_t)LW / 4 * 64;                 // input dwords per wave-chunk
+    const size_t nchunks = in_dwords / chunk_dw;
+    rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
+    size_t c = wave;
+    if (c >= nchunks) return;
+    u4 cur = { 0, 0, 0, 0 };
+    auto ld = [&](size_t cc) { u4 v = { 0, 0, 0, 0 };
+        if (LW == 4) v.x = in[cc * chunk_dw + lane];
+        else {
+#pragma unroll
+            for (int k = 0; k < LW / 16; ++k) { u4 w = reinterpret_cast<const u4 *>(in + cc * chunk_dw)[k * 64 + lane]; v.x ^= w.x; v.y ^= w.y; v.z ^= w.z; v.w ^= w.w; }
+        }
+        return v; };
+    cur = ld(c);
+    if (PREFETCH) asm volatile("" : "+v"(cur));
+    for (;;) {
+        const size_t n = c + nwaves;
+        const bool more = n < nchunks;
+        u4 nxt = cur;
+        if (PREFETCH) nxt = ld(more ? n : c);
+        const float f = (float)(cur.x & 0xfffu) * (1.0f / 4096.0f) + (float)(cur.w & 1u);
+        const rd_f4 val = { f, f, f, 1.0f };
+        // output: 8x the input bytes, contiguous: LW*8/16 float4 per lane
+#pragma unroll
+        for (uint32_t k = 0; k < LW * 8 / 16; ++k)
+            __builtin_nontemporal_store(val, o + (c * (LW * 8 / 16) + k) * 64u + lane);
+        if (!more) break;
+        if (!PREFETCH) nxt = ld(n);
+        c = n; cur = nxt;
+    }
+}
+
 typedef float rd_f2 __attribute__((ext_vector_type(2)));
 // ---- VALU calibration: ITER x 16 independent ops per lane -----------------------------------------
 template <int KIND>
@@ -179,6 +265,15 @@ int main(int argc, char **argv)
     ADD("full plain nohist 1024x512", M_COMPUTE | M_STORE | M_PLAIN_ST, 1024, 512);
     ADD("full ldsT nt nohist 1024x512", M_COMPUTE | M_STORE | M_LDS_T, 1024, 512);
     ADD("compute only 1024x512", M_COMPUTE, 1024, 512);
+    ADD("lite1 compute only x512", M_COMPUTE | M_LITE, 1024, 512);
+    ADD("lite1 + ldsT st x512", M_COMPUTE | M_LITE | M_STORE | M_LDS_T, 1024, 512);
+    ADD("lite2 compute only x512", M_COMPUTE | M_LITE2, 1024, 512);
+    ADD("lite2 + ldsT st x512", M_COMPUTE | M_LITE2 | M_STORE | M_LDS_T, 1024, 512);
+    ADD("lite2 + ldsT st x256", M_COMPUTE | M_LITE2 | M_STORE | M_LDS_T, 1024, 256);
+    ADD("lite2 + ldsT st x1024", M_COMPUTE | M_LITE2 | M_STORE | M_LDS_T, 1024, 1024);
+    ADD("compute+fake contig st x512", M_COMPUTE | M_STORE | M_FAKE_CONTIG, 1024, 512);
+    ADD("compute+ldsT no global st x512", M_COMPUTE | M_STORE | M_LDS_T | M_LDS_ONLY, 1024, 512);
+    ADD("fake contig st only x512", M_STORE | M_FAKE_CONTIG, 1024, 512);
     ADD("compute+hist 1024x256", M_COMPUTE | M_HIST, 1024, 256);
     ADD("store only nt 1024x512", M_STORE, 1024, 512);
     ADD("store only plain 1024x512", M_STORE | M_PLAIN_ST, 1024, 512);
@@ -186,18 +281,46 @@ int main(int argc, char **argv)
     ADD("store+hist nt 1024x256", M_STORE | M_HIST, 1024, 256);
     unsigned long long *slab64; CK(hipMalloc((void **)&slab64, (size_t)RD_MAX_BLOCKS * 768 * 8)); CK(hipMemset(slab64, 0, (size_t)RD_MAX_BLOCKS * 768 * 8));
     const uint32_t tpu = (qpr + 63) / 64;
-#define PROD(NAME, FMT, HIST, BLOCKS, OUTP, S32, S64)                                                   \
+#define PROD(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                   \
     vs.push_back({ NAME, [&, qpr, tpu](int k) { const uint32_t nw = (BLOCKS) * RD_WAVES;               \
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
                            W, H, 0u, H / 2 + 1, tpu, nw / tpu, nw % tpu, u, S32, S64); }, {} })
-    PROD("PRODUCT f32 hist slab32 x256", 0, true, 256, 0, slab, (unsigned long long *)nullptr);
-    PROD("PRODUCT f32 hist slab64 x256", 0, true, 256, 0, (uint32_t *)nullptr, slab64);
-    PROD("PRODUCT f32 nohist x256", 0, false, 256, 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
-    PROD("PRODUCT f32 nohist x512", 0, false, 512, 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
-    PROD("PRODUCT f16 hist x256", 1, true, 256, 0, (uint32_t *)nullptr, slab64);
-    PROD("PRODUCT f16 nohist x512", 1, false, 512, 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
-    PROD("PRODUCT u8 hist x256", 2, true, 256, 0, (uint32_t *)nullptr, slab64);
-    PROD("PRODUCT u8 nohist x512", 2, false, 512, 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    PROD("PRODUCT f32 hist slab32 x256", 0, true, 256, false, slab, (unsigned long long *)nullptr);
+    PROD("PRODUCT f32 hist slab64 x256", 0, true, 256, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f32 hist slab64 x256 BURST", 0, true, 256, true, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f32 nohist x256", 0, false, 256, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    PROD("PRODUCT f32 nohist x512", 0, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    PROD("PRODUCT f32 nohist x512 BURST", 0, false, 512, true, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    PROD("PRODUCT f16 hist x256", 1, true, 256, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f16 hist x256 BURST", 1, true, 256, true, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f16 nohist x512", 1, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    PROD("PRODUCT u8 hist x256", 2, true, 256, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT u8 nohist x512", 2, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+#define SPAT(NAME, ROWS, NT, LOADS, BLOCKS) vs.push_back({ NAME, [&](int k) { hipLaunchKernelGGL((mb_store_pat<ROWS, NT, LOADS>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], dout[k % NOUT], W, H); }, {} })
+    SPAT("pat 2rows nt loads x512", 2, true, true, 512);
+    SPAT("pat 2rows nt noloads x512", 2, true, false, 512);
+    SPAT("pat 2rows plain loads x512", 2, false, true, 512);
+    SPAT("pat 2rows plain noloads x512", 2, false, false, 512);
+    SPAT("pat 1row nt loads x512", 1, true, true, 512);
+    SPAT("pat 1row nt noloads x512", 1, true, false, 512);
+    SPAT("pat 2rows nt loads x256", 2, true, true, 256);
+    SPAT("pat 2rows nt loads x1024", 2, true, true, 1024);
+    SPAT("pat 2rows nt loads x2048", 2, true, true, 2048);
+#define MIX(NAME, LW, PF, BLOCKS) vs.push_back({ NAME, [&](int k) { hipLaunchKernelGGL((mb_mix<LW, PF>), dim3(BLOCKS), dim3(1024), 0, s, (const uint32_t *)din[k % NIN], dout[k % NOUT], in_bytes / 4); }, {} })
+    MIX("mix 1:8 load4B prefetch x512", 4, true, 512);
+    MIX("mix 1:8 load4B noprefetch x512", 4, false, 512);
+    MIX("mix 1:8 load16B prefetch x512", 16, true, 512);
+    MIX("mix 1:8 load16B noprefetch x512", 16, false, 512);
+    MIX("mix 1:8 load16B prefetch x2048", 16, true, 2048);
+    MIX("mix 1:8 load4B prefetch x2048", 4, true, 2048);
+    MIX("mix 1:8 load64B prefetch x512", 64, true, 512);
+    MIX("mix 1:8 load64B prefetch x2048", 64, true, 2048);
+    MIX("mix 1:8 load256B prefetch x512", 256, true, 512);
+    MIX("mix 1:8 load256B prefetch x2048", 256, true, 2048);
+#define MIXC(NAME, LW, PF, BLOCKS) vs.push_back({ NAME, [&](int k) { hipLaunchKernelGGL((mb_mix<LW, PF>), dim3(BLOCKS), dim3(1024), 0, s, (const uint32_t *)din[0], dout[k % NOUT], in_bytes / 4); }, {} })
+    MIXC("mix 1:8 SAME input load16B x512", 16, true, 512);
+    MIXC("mix 1:8 SAME input load4B x512", 4, true, 512);
+    MIXC("mix 1:8 SAME input load16B x2048", 16, true, 2048);
     vs.push_back({ "fill contiguous nt", [&](int k) { hipLaunchKernelGGL(mb_fill, dim3(2048), dim3(1024), 0, s, dout[k % NOUT], out_bytes / 16, 1); }, {} });
     vs.push_back({ "fill contiguous plain", [&](int k) { hipLaunchKernelGGL(mb_fill, dim3(2048), dim3(1024), 0, s, dout[k % NOUT], out_bytes / 16, 0); }, {} });
 
@@ -228,7 +351,7 @@ int main(int argc, char **argv)
         }
     }
     if (argc > 2) {   // sustained run of the full kernel: burst vs throttled clock
-        auto &v = vs[13];   // PRODUCT f32 hist slab64
+        auto &v = vs[16];   // PRODUCT f32 hist slab64
         for (int w = 0; w < atoi(argv[2]); ++w) {
             CK(hipEventRecord(e0, s)); for (int k = 0; k < 256; ++k) v.run(k); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
