@@ -1,0 +1,185 @@
+// rawdev.hpp -- C++17 host mirror of the reference interface for the develop path, header-only,
+// over the C ABI of rawdev.h.  The reference's host is Rust (no toolchain in this image), so the
+// host side above the ABI is written in C++ with the reference's names, argument meaning and error
+// behaviour:
+//
+//   rawdev::EditParams      <- state::edit::EditParams   (reference src/state/edit.rs:15-122)
+//   rawdev::RenderPipeline  <- gpu::RenderPipeline       (reference src/gpu/pipeline.rs:81-100, :112-737)
+//
+// `Result<T, String>` becomes rawdev::Error (an exception carrying the rd_status and the message of
+// rd_last_error()); `Vec<u8>` becomes std::vector<uint8_t>; `[[u32; 256]; 3]` becomes
+// std::array<std::array<uint32_t, 256>, 3>.  Nothing here computes pixels: every render is a HIP
+// kernel launch inside librawdev.so.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rawdev.h"
+
+namespace rawdev {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc)
+{
+    if (rc != RD_OK) throw Error(rc, rd_last_error());
+}
+
+// state::edit::EditParams.  Field order = serde order = uniform-block order.
+struct EditParams : rd_edit_params {
+    EditParams() { rd_edit_params_default(this); }                       // Default (edit.rs:79-96)
+    static EditParams new_() { return EditParams(); }                    // new() (edit.rs:100-102)
+
+    static constexpr const char *kFields[10] = { "exposure", "contrast", "highlights", "shadows", "whites",
+                                                 "blacks", "vibrance", "saturation", "temperature", "tint" };
+    float *begin() { return &exposure; }
+    const float *begin() const { return &exposure; }
+
+    bool operator==(const EditParams &o) const { return std::memcmp(begin(), o.begin(), 10 * sizeof(float)) == 0; }
+    bool is_unedited() const { return *this == EditParams(); }           // edit.rs:115-117
+    void reset() { *this = EditParams(); }                               // edit.rs:120-122
+
+    // to_json (edit.rs:105-107): {"exposure":0.0,...} in field order, shortest round-trip f32.
+    std::string to_json() const
+    {
+        std::string s = "{";
+        for (int i = 0; i < 10; ++i) {
+            char buf[64];
+            const float v = begin()[i];
+            if (!std::isfinite(v)) std::snprintf(buf, sizeof buf, "null");
+            else {
+                int prec = 1;
+                for (; prec < 10; ++prec) {                              // shortest %.Ng that round-trips
+                    std::snprintf(buf, sizeof buf, "%.*g", prec, (double)v);
+                    if (std::strtof(buf, nullptr) == v) break;
+                }
+                if (!std::strpbrk(buf, ".eE")) std::strcat(buf, ".0");
+            }
+            s += std::string(i ? "," : "") + "\"" + kFields[i] + "\":" + buf;
+        }
+        return s + "}";
+    }
+
+    // from_json (edit.rs:110-112): every field required (serde derive), unknown fields ignored.
+    static EditParams from_json(const std::string &text)
+    {
+        EditParams p;
+        for (int i = 0; i < 10; ++i) {
+            const std::string key = std::string("\"") + kFields[i] + "\"";
+            size_t k = text.find(key);
+            if (k == std::string::npos) throw Error(RD_ERR_INVALID_ARG, std::string("missing field `") + kFields[i] + "`");
+            k = text.find(':', k + key.size());
+            if (k == std::string::npos) throw Error(RD_ERR_INVALID_ARG, "malformed JSON");
+            char *end = nullptr;
+            const float v = std::strtof(text.c_str() + k + 1, &end);
+            if (end == text.c_str() + k + 1) throw Error(RD_ERR_INVALID_ARG, std::string("invalid value for `") + kFields[i] + "`");
+            p.begin()[i] = v;
+        }
+        return p;
+    }
+};
+
+using Histogram = std::array<std::array<uint32_t, 256>, 3>;
+
+// gpu::RenderPipeline.  Move-only owner of an rd_pipeline; share it across threads by reference or
+// shared_ptr exactly like the reference shares Arc<RenderPipeline> (main.rs:1054, :1749).
+class RenderPipeline {
+public:
+    // pub fields of the reference (pipeline.rs:89-96)
+    uint32_t width = 0, height = 0, preview_width = 0, preview_height = 0;
+    int64_t image_id = 0;
+    uint32_t histogram_width = 0, histogram_height = 0;
+
+    // RenderPipeline::new (pipeline.rs:114-122).  Throws Error where the reference returns Err(String).
+    static RenderPipeline new_(int64_t image_id, const std::vector<uint16_t> &raw_data, uint32_t width,
+                               uint32_t height, const EditParams &params, const std::array<float, 4> &wb_multipliers,
+                               const std::array<float, 9> &color_matrix, int device = 0)
+    {
+        if (raw_data.size() != (size_t)width * height)
+            throw Error(RD_ERR_INVALID_ARG, "raw_data length does not match width*height");
+        RenderPipeline p;
+        check(rd_pipeline_create(device, image_id, raw_data.data(), width, height, &params, wb_multipliers.data(),
+                                 color_matrix.data(), &p.h_));
+        rd_info info;
+        check(rd_pipeline_info(p.h_, &info));
+        p.width = info.width; p.height = info.height;
+        p.preview_width = info.preview_width; p.preview_height = info.preview_height;
+        p.histogram_width = info.histogram_width; p.histogram_height = info.histogram_height;
+        p.image_id = info.image_id;
+        return p;
+    }
+
+    RenderPipeline(RenderPipeline &&o) noexcept { *this = std::move(o); }
+    RenderPipeline &operator=(RenderPipeline &&o) noexcept
+    {
+        if (this != &o) {
+            rd_pipeline_destroy(h_);
+            width = o.width; height = o.height; preview_width = o.preview_width; preview_height = o.preview_height;
+            image_id = o.image_id; histogram_width = o.histogram_width; histogram_height = o.histogram_height;
+            h_ = o.h_;
+            o.h_ = nullptr;
+        }
+        return *this;
+    }
+    RenderPipeline(const RenderPipeline &) = delete;
+    RenderPipeline &operator=(const RenderPipeline &) = delete;
+    ~RenderPipeline() { rd_pipeline_destroy(h_); }
+
+    void update_uniforms(const EditParams &p) const { check(rd_update_uniforms(h_, &p)); }                // :367
+    void update_uniforms_with_zoom(const EditParams &p, float zoom, float pan_x, float pan_y) const      // :373
+    {
+        check(rd_update_uniforms_with_zoom(h_, &p, zoom, pan_x, pan_y));
+    }
+    std::vector<uint8_t> render_to_bytes() const                                                        // :442
+    {
+        std::vector<uint8_t> v((size_t)preview_width * preview_height * 4);
+        check(rd_render_to_bytes(h_, v.data(), v.size()));
+        return v;
+    }
+    std::vector<uint8_t> render_full_res_to_bytes() const                                               // :526
+    {
+        std::vector<uint8_t> v((size_t)width * height * 4);
+        check(rd_render_full_res_to_bytes(h_, v.data(), v.size()));
+        return v;
+    }
+    std::vector<uint8_t> render_to_histogram_bytes() const                                              // :615
+    {
+        std::vector<uint8_t> v((size_t)histogram_width * histogram_height * 4);
+        check(rd_render_to_histogram_bytes(h_, v.data(), v.size()));
+        return v;
+    }
+    Histogram calculate_histogram(const std::vector<uint8_t> &rgba_bytes) const                         // :720
+    {
+        Histogram h;
+        check(rd_calculate_histogram(h_, rgba_bytes.data(), rgba_bytes.size() - rgba_bytes.size() % 4, &h[0][0]));
+        return h;
+    }
+    std::pair<uint32_t, uint32_t> dimensions() const { return { width, height }; }                      // :609
+
+    // extension: the f32 surface the north-star asks for (vec4(color,1.0), shaders.rs:264-266)
+    std::vector<float> render_f32(uint32_t out_w, uint32_t out_h, Histogram *hist = nullptr) const
+    {
+        std::vector<float> v((size_t)out_w * out_h * 4);
+        check(rd_render(h_, out_w, out_h, RD_FMT_RGBA_F32, v.data(), v.size() * sizeof(float), hist ? &(*hist)[0][0] : nullptr));
+        return v;
+    }
+    rd_pipeline *handle() const { return h_; }
+
+private:
+    RenderPipeline() = default;
+    rd_pipeline *h_ = nullptr;
+};
+
+}  // namespace rawdev
