@@ -48,6 +48,14 @@ typedef enum rd_format {
     RD_FMT_RGBA_U8 = 2   /*  4 B/px, trunc(x*255 + 0.5), alpha 255 */
 } rd_format;
 
+/* Arithmetic of the colour stack.  Both are restatements of the same WGSL text
+ * within the latitude WGSL leaves (contraction unspecified, division 2.5 ULP) and each is checked bit
+ * for bit against the oracle in the same mode.
+ *   STRICT     (default) literal operation order, no contraction, IEEE-correct division;
+ *   CONTRACTED every a*b+c becomes one fma and x/d (d uniform) becomes x*RN(1/d) -- what an AMD shader
+ *              compiler emits for the reference's shader; ~20 % fewer VALU instructions. */
+typedef enum rd_math_mode { RD_MATH_STRICT = 0, RD_MATH_CONTRACTED = 1 } rd_math_mode;
+
 /* state::edit::EditParams (src/state/edit.rs:15-77): ten f32 in this order; #[repr(C)]-compatible. */
 typedef struct rd_edit_params {
     float exposure;    /* stops, UI range [-5, 5]          (main.rs:1624-1660 for all ranges) */
@@ -103,6 +111,8 @@ int rd_pipeline_info(const rd_pipeline *p, rd_info *out);
 /* Extension: integer black level subtracted (saturating) before normalisation.
  * 0 (default) is the reference, which subtracts nothing (shaders.rs:106-110). */
 int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t black_level);
+/* Extension: select the arithmetic (rd_math_mode); RD_MATH_STRICT is the default. */
+int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t math_mode);
 
 /* update_uniforms (pipeline.rs:367) == update_uniforms_with_zoom(params, 1, 0, 0). */
 int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params);
@@ -147,6 +157,7 @@ typedef struct rd_frame {
 int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format,
                     uint32_t with_histogram, rd_batch **out);
 void rd_batch_destroy(rd_batch *b);
+int rd_batch_set_math_mode(rd_batch *b, uint32_t math_mode); /* rd_math_mode, default RD_MATH_STRICT */
 /* Enqueue one fused demosaic+develop(+histogram) launch per frame on `stream`, full resolution,
  * zoom 1 / pan 0 (the export map).  Histogram counts accumulate inside the context in u64.
  * `row_bands` > 1 splits every frame into that many row-band launches (config 5's tiled

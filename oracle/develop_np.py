@@ -51,6 +51,7 @@ class Uniforms:
     pan_x: float = 0.0
     pan_y: float = 0.0
     black_level: int = 0
+    math_mode: str = "strict"      # "strict" (literal WGSL order) or "contracted" (fma + reciprocal multiply)
 
 
 def fma32(a, b, c):
@@ -216,6 +217,49 @@ def colour_stack(r, g, b, u: Uniforms, pow_mode="pinned"):
     return [c.astype(F) for c in out]
 
 
+def _dot709_fma(r, g, b):
+    return fma32(b, REC709[2], fma32(g, REC709[1], r * REC709[0]))
+
+
+def colour_stack_contracted(r, g, b, u: Uniforms, pow_mode="pinned"):
+    """Same shader, every mul+add contracted to one fma, levels division as x*RN(1/d)."""
+    powf = pow_pinned if pow_mode == "pinned" else pow_libm
+    one, half = F(1.0), F(0.5)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        r = r * F(u.wb[0]); g = g * F(u.wb[1]); b = b * F(u.wb[2])
+        r = r * fma32(F(u.temperature), F(0.3), one)
+        b = b * fma32(-F(u.temperature), F(0.3), one)
+        g = g * fma32(F(u.tint), F(0.3), one)
+        m = [F(x) for x in u.cm]
+        x = fma32(m[6], b, fma32(m[3], g, m[0] * r))
+        y = fma32(m[7], b, fma32(m[4], g, m[1] * r))
+        z = fma32(m[8], b, fma32(m[5], g, m[2] * r))
+        em = powf(np.array([2.0], F), F(u.exposure))[0]
+        r = x * em; g = y * em; b = z * em
+        L = _dot709_fma(r, g, b)
+        hl = fma32(L, F(u.highlights), one)
+        r = r * hl; g = g * hl; b = b * hl
+        sh = fma32(one - L, F(u.shadows), one)
+        r = r * sh; g = g * sh; b = b * sh
+        cf = one + (F(u.contrast) / F(100.0))
+        r = fma32(r - half, cf, half); g = fma32(g - half, cf, half); b = fma32(b - half, cf, half)
+        den = (F(u.whites) - F(u.blacks)) + F(0.0001)
+        rden = one / den
+        r = (r - F(u.blacks)) * rden; g = (g - F(u.blacks)) * rden; b = (b - F(u.blacks)) * rden
+        Y = _dot709_fma(r, g, b)
+        s = one + (F(u.saturation) / F(100.0))
+        ys = Y * (one - s)
+        r = fma32(r, s, ys); g = fma32(g, s, ys); b = fma32(b, s, ys)
+        sat = np.fmax(r, np.fmax(g, b)) - np.fmin(r, np.fmin(g, b))
+        a2 = fma32(F(u.vibrance), one - sat, one)
+        Y2 = _dot709_fma(r, g, b)
+        yv = Y2 * (one - a2)
+        r = fma32(r, a2, yv); g = fma32(g, a2, yv); b = fma32(b, a2, yv)
+        r = powf(r, INV_GAMMA); g = powf(g, INV_GAMMA); b = powf(b, INV_GAMMA)
+        out = [np.fmin(np.fmax(c, F(0.0)), F(1.0)) for c in (r, g, b)]
+    return [c.astype(F) for c in out]
+
+
 def render_f32(cfa, u: Uniforms, tw=None, th=None, pow_mode="pinned"):
     """(h,w) uint16 -> (th,tw,4) float32, alpha = 1."""
     cfa = np.asarray(cfa, np.uint16)
@@ -224,7 +268,8 @@ def render_f32(cfa, u: Uniforms, tw=None, th=None, pow_mode="pinned"):
     th = h if th is None else th
     PX, PY, inside = pixel_map(w, h, tw, th, u.zoom, u.pan_x, u.pan_y)
     r, g, b = demosaic(cfa, PX, PY, u.black_level)
-    r, g, b = colour_stack(r, g, b, u, pow_mode)
+    stack = colour_stack_contracted if u.math_mode == "contracted" else colour_stack
+    r, g, b = stack(r, g, b, u, pow_mode)
     out = np.empty((th, tw, 4), F)
     out[..., 0] = np.where(inside, r, F(0))
     out[..., 1] = np.where(inside, g, F(0))

@@ -189,6 +189,55 @@ static void colour_stack(const ref_uniforms *u, int pow_mode, float c[3])
     c[2] = fminf(fmaxf(b, 0.0f), 1.0f);
 }
 
+/* shaders.rs:192-266 with every mul+add of the expression tree contracted to one fma and the levels
+ * division done as a multiplication by the correctly rounded reciprocal (REF_MATH_CONTRACTED). */
+static inline float dot709_fma(float r, float g, float b)
+{
+    return fmaf(b, 0.0722f, fmaf(g, 0.7152f, r * 0.2126f));
+}
+
+static void colour_stack_contracted(const ref_uniforms *u, int pow_mode, float c[3])
+{
+    const ref_edit_params *p = &u->p;
+    float r = c[0], g = c[1], b = c[2];
+    r = r * u->wb[0]; g = g * u->wb[1]; b = b * u->wb[2];                          /* :195 */
+    r = r * fmaf(p->temperature, 0.3f, 1.0f);                                      /* :200 */
+    b = b * fmaf(-p->temperature, 0.3f, 1.0f);                                     /* :201  1 - t*0.3 */
+    g = g * fmaf(p->tint, 0.3f, 1.0f);                                             /* :205 */
+    const float *m = u->cm;                                                        /* :209-214 (columns) */
+    float x = fmaf(m[6], b, fmaf(m[3], g, m[0] * r));
+    float y = fmaf(m[7], b, fmaf(m[4], g, m[1] * r));
+    float z = fmaf(m[8], b, fmaf(m[5], g, m[2] * r));
+    float em = ref_powf(2.0f, p->exposure, pow_mode);                              /* :217-218 */
+    r = x * em; g = y * em; b = z * em;
+    float L = dot709_fma(r, g, b);                                                 /* :222 */
+    float hl = fmaf(L, p->highlights, 1.0f);                                       /* :226 */
+    r = r * hl; g = g * hl; b = b * hl;
+    float sh = fmaf(1.0f - L, p->shadows, 1.0f);                                   /* :230 */
+    r = r * sh; g = g * sh; b = b * sh;
+    float cf = 1.0f + (p->contrast / 100.0f);                                      /* :233 (uniform) */
+    r = fmaf(r - 0.5f, cf, 0.5f); g = fmaf(g - 0.5f, cf, 0.5f); b = fmaf(b - 0.5f, cf, 0.5f);
+    float den = (p->whites - p->blacks) + 0.0001f;                                 /* :239 (uniform) */
+    float rden = 1.0f / den;
+    r = (r - p->blacks) * rden; g = (g - p->blacks) * rden; b = (b - p->blacks) * rden;
+    float Y = dot709_fma(r, g, b);                                                 /* :243-247 */
+    float s = 1.0f + (p->saturation / 100.0f);
+    float ys = Y * (1.0f - s);
+    r = fmaf(r, s, ys); g = fmaf(g, s, ys); b = fmaf(b, s, ys);
+    float sat = fmaxf(r, fmaxf(g, b)) - fminf(r, fminf(g, b));                     /* :251 */
+    float a2 = fmaf(p->vibrance, 1.0f - sat, 1.0f);                                /* :254, :257  1 + vibrance*(1-sat) */
+    float Y2 = dot709_fma(r, g, b);                                                /* :256 */
+    float yv = Y2 * (1.0f - a2);
+    r = fmaf(r, a2, yv); g = fmaf(g, a2, yv); b = fmaf(b, a2, yv);
+    const float inv_gamma = (float)(1.0 / 2.2);                                    /* :261 */
+    r = ref_powf(r, inv_gamma, pow_mode);
+    g = ref_powf(g, inv_gamma, pow_mode);
+    b = ref_powf(b, inv_gamma, pow_mode);
+    c[0] = fminf(fmaxf(r, 0.0f), 1.0f);                                            /* :264 */
+    c[1] = fminf(fmaxf(g, 0.0f), 1.0f);
+    c[2] = fminf(fmaxf(b, 0.0f), 1.0f);
+}
+
 /* shaders.rs:23-60 (vs_main, evaluated at the pixel centre) + :174-187 (bounds, pixel_coords). */
 void ref_pixel(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
                uint32_t tw, uint32_t th, uint32_t i, uint32_t j, int pow_mode, float rgba[4])
@@ -208,7 +257,8 @@ void ref_pixel(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *
     if (py > (int32_t)h - 1) py = (int32_t)h - 1;
     float c[3];
     debayer(cfa, (int32_t)w, (int32_t)h, px, py, u->black_level, c);
-    colour_stack(u, pow_mode, c);
+    if (u->math_mode == REF_MATH_CONTRACTED) colour_stack_contracted(u, pow_mode, c);
+    else colour_stack(u, pow_mode, c);
     rgba[0] = c[0]; rgba[1] = c[1]; rgba[2] = c[2];
 }
 

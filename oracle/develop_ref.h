@@ -44,7 +44,14 @@ typedef struct {
     float cm[9];  /* host row-major; the shader consumes the rows as COLUMNS (shaders.rs:209-214) */
     float zoom, pan_x, pan_y;
     uint32_t black_level; /* extension, 0 = reference behaviour (the reference subtracts nothing) */
+    uint32_t math_mode;   /* REF_MATH_STRICT (literal WGSL order, default) or REF_MATH_CONTRACTED */
 } ref_uniforms;
+
+/* REF_MATH_CONTRACTED restates the same shader the way an AMD shader compiler is allowed to (and does)
+ * lower it: every a*b+c of the WGSL expression tree becomes one fma, and x/d by the uniform d becomes
+ * x*RN(1/d) (WGSL permits both: contraction is unspecified, division is 2.5 ULP).  The exact sequence
+ * is spelled out in colour_stack_contracted(); DESIGN.md section 3b. */
+enum { REF_MATH_STRICT = 0, REF_MATH_CONTRACTED = 1 };
 
 enum { REF_POW_PINNED = 0, REF_POW_LIBM = 1 };
 

@@ -24,11 +24,12 @@ class RefEditParams(C.Structure):
 class RefUniforms(C.Structure):
     _fields_ = [("p", RefEditParams), ("wb", C.c_float * 4), ("cm", C.c_float * 9),
                 ("zoom", C.c_float), ("pan_x", C.c_float), ("pan_y", C.c_float),
-                ("black_level", C.c_uint32)]
+                ("black_level", C.c_uint32), ("math_mode", C.c_uint32)]
 
 
 PARAM_NAMES = [n for n, _ in RefEditParams._fields_]
 POW_PINNED, POW_LIBM = 0, 1
+MATH_STRICT, MATH_CONTRACTED = 0, 1
 
 
 def build(force: bool = False) -> str:
@@ -69,7 +70,7 @@ def lib():
 
 
 def make_uniforms(params=None, wb=(1, 1, 1, 1), cm=(1, 0, 0, 0, 1, 0, 0, 0, 1),
-                  zoom=1.0, pan_x=0.0, pan_y=0.0, black_level=0) -> RefUniforms:
+                  zoom=1.0, pan_x=0.0, pan_y=0.0, black_level=0, math_mode=MATH_STRICT) -> RefUniforms:
     """params: dict of slider name -> value (missing = EditParams::default(), state/edit.rs:81-95)."""
     u = RefUniforms()
     lib().ref_default_params(C.byref(u.p))
@@ -80,6 +81,7 @@ def make_uniforms(params=None, wb=(1, 1, 1, 1), cm=(1, 0, 0, 0, 1, 0, 0, 0, 1),
     u.wb[:] = [float(x) for x in wb]
     u.cm[:] = [float(x) for x in cm]
     u.zoom, u.pan_x, u.pan_y, u.black_level = float(zoom), float(pan_x), float(pan_y), int(black_level)
+    u.math_mode = int(math_mode)
     return u
 
 

@@ -10,6 +10,7 @@ from .build import LIB_PATH
 
 RD_OK = 0
 FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8 = 0, 1, 2
+MATH_STRICT, MATH_CONTRACTED = 0, 1
 BYTES_PER_PIXEL = {FMT_RGBA_F32: 16, FMT_RGBA_F16: 8, FMT_RGBA_U8: 4}
 
 
@@ -57,6 +58,7 @@ PROTOTYPES = {
     "rd_pipeline_destroy": (None, [_VP]),
     "rd_pipeline_info": (_I, [_VP, C.POINTER(RdInfo)]),
     "rd_pipeline_set_black_level": (_I, [_VP, _U32]),
+    "rd_pipeline_set_math_mode": (_I, [_VP, _U32]),
     "rd_update_uniforms": (_I, [_VP, C.POINTER(RdEditParams)]),
     "rd_update_uniforms_with_zoom": (_I, [_VP, C.POINTER(RdEditParams), C.c_float, C.c_float, C.c_float]),
     "rd_render_to_bytes": (_I, [_VP, _VP, _SZ]),
@@ -67,6 +69,7 @@ PROTOTYPES = {
     "rd_render_device": (_I, [_VP, _U32, _U32, _U32, _VP, _VP, _VP]),
     "rd_batch_create": (_I, [_I, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),
     "rd_batch_destroy": (None, [_VP]),
+    "rd_batch_set_math_mode": (_I, [_VP, _U32]),
     "rd_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32, _VP]),
     "rd_batch_histogram": (_I, [_VP, _VP, _VP]),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),

@@ -39,12 +39,15 @@ def allreduce_histogram(hist64):
 class BatchExporter:
     """rd_batch: fused demosaic+develop(+histogram) launches for same-sized frames on one device."""
 
-    def __init__(self, device: int, width: int, height: int, fmt: int, with_histogram: bool = True):
+    def __init__(self, device: int, width: int, height: int, fmt: int, with_histogram: bool = True,
+                 math_mode: int = _lib.MATH_STRICT):
         self._h = C.c_void_p()
         self.device, self.width, self.height, self.fmt = device, int(width), int(height), int(fmt)
         self.with_histogram = bool(with_histogram)
         check(_lib.lib().rd_batch_create(device, self.width, self.height, self.fmt,
                                          1 if with_histogram else 0, C.byref(self._h)))
+        if math_mode != _lib.MATH_STRICT:
+            check(_lib.lib().rd_batch_set_math_mode(self._h, int(math_mode)))
 
     @staticmethod
     def make_frames(cfa_ptrs: Sequence[int], out_ptrs: Sequence[int], params: Sequence[EditParams],

@@ -138,11 +138,11 @@ static bool rd_identity_map(uint32_t n)
 
 struct rd_launch_cfg {
     int n_cu = 256;
-    uint32_t wg_per_cu_hist = 1;     // 96 KiB of LDS per workgroup
+    uint32_t wg_per_cu_hist = 2;     // 24 KiB histogram + 48 KiB store stage per workgroup
     uint32_t wg_per_cu_plain = 2;    // 2 x 1024 threads = the CU's 32 waves
 };
 
-template <int FMT, bool HIST>
+template <int FMT, bool HIST, int MATH>
 static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t unit0,
                               uint32_t unit1, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
                               unsigned long long *slab64, hipStream_t s)
@@ -150,33 +150,37 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
     const uint32_t nwaves = blocks * RD_WAVES;
     if (W % 128u == 0)
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
                            unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
     else
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false, MATH>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
                            unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
 }
 
-template <int FMT, bool HIST>
+template <int FMT, bool HIST, int MATH>
 static void rd_launch_map_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t tw,
                             uint32_t th, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
                             unsigned long long *slab64, hipStream_t s)
 {
-    hipLaunchKernelGGL((rd_develop_map<FMT, HIST>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H, tw,
+    hipLaunchKernelGGL((rd_develop_map<FMT, HIST, MATH>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H, tw,
                        th, u, slab32, slab64);
 }
 
-#define RD_DISPATCH(fn, fmt, hist, ...)                                                           \
+#define RD_DISPATCH3(fn, FMT, hist, math, ...)                                                    \
     do {                                                                                          \
         if (hist) {                                                                               \
-            if (fmt == RD_FMT_RGBA_F32) fn<RD_FMT_RGBA_F32, true>(__VA_ARGS__);                   \
-            else if (fmt == RD_FMT_RGBA_F16) fn<RD_FMT_RGBA_F16, true>(__VA_ARGS__);              \
-            else fn<RD_FMT_RGBA_U8, true>(__VA_ARGS__);                                           \
+            if (math == RD_MATH_CONTRACTED) fn<FMT, true, RD_MATH_CONTRACTED>(__VA_ARGS__);       \
+            else fn<FMT, true, RD_MATH_STRICT>(__VA_ARGS__);                                      \
         } else {                                                                                  \
-            if (fmt == RD_FMT_RGBA_F32) fn<RD_FMT_RGBA_F32, false>(__VA_ARGS__);                  \
-            else if (fmt == RD_FMT_RGBA_F16) fn<RD_FMT_RGBA_F16, false>(__VA_ARGS__);             \
-            else fn<RD_FMT_RGBA_U8, false>(__VA_ARGS__);                                          \
+            if (math == RD_MATH_CONTRACTED) fn<FMT, false, RD_MATH_CONTRACTED>(__VA_ARGS__);      \
+            else fn<FMT, false, RD_MATH_STRICT>(__VA_ARGS__);                                     \
         }                                                                                         \
+    } while (0)
+#define RD_DISPATCH(fn, fmt, hist, math, ...)                                                     \
+    do {                                                                                          \
+        if (fmt == RD_FMT_RGBA_F32) RD_DISPATCH3(fn, RD_FMT_RGBA_F32, hist, math, __VA_ARGS__);   \
+        else if (fmt == RD_FMT_RGBA_F16) RD_DISPATCH3(fn, RD_FMT_RGBA_F16, hist, math, __VA_ARGS__); \
+        else RD_DISPATCH3(fn, RD_FMT_RGBA_U8, hist, math, __VA_ARGS__);                           \
     } while (0)
 
 static uint32_t rd_blocks_for(const rd_launch_cfg &cfg, uint64_t items, bool hist)
@@ -194,7 +198,7 @@ static size_t rd_align_for(uint32_t) { return 16; }   // every surface is writte
 // (the slab rows written) through *blocks_out.  use_quads selects the export kernel.
 static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint32_t W, uint32_t H,
                              uint32_t tw, uint32_t th, uint32_t fmt, void *out, const rd_ku &u,
-                             bool use_quads, uint32_t unit0, uint32_t unit1, bool hist,
+                             bool use_quads, uint32_t unit0, uint32_t unit1, bool hist, uint32_t math,
                              uint32_t *slab32, unsigned long long *slab64, uint32_t fixed_blocks,
                              hipStream_t s, uint32_t *blocks_out)
 {
@@ -203,12 +207,12 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
         const uint64_t items = (uint64_t)(unit1 - unit0) * (((W >> 1) + 63u) / 64u) * 64u;   // lanes
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
-        RD_DISPATCH(rd_launch_quads_t, fmt, hist, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, s);
+        RD_DISPATCH(rd_launch_quads_t, fmt, hist, math, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, s);
     } else {
         const uint64_t items = (uint64_t)tw * th;
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "target too large for 32-bit pixel index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
-        RD_DISPATCH(rd_launch_map_t, fmt, hist, cfa, out, W, H, tw, th, blocks, u, slab32, slab64, s);
+        RD_DISPATCH(rd_launch_map_t, fmt, hist, math, cfa, out, W, H, tw, th, blocks, u, slab32, slab64, s);
     }
     RD_HIP(hipGetLastError());
     if (blocks_out) *blocks_out = blocks;
@@ -229,6 +233,7 @@ struct rd_pipeline {
     float wb[4]{}, cm[9]{};
     float zoom = 1.0f, pan_x = 0.0f, pan_y = 0.0f;
     uint32_t black_level = 0;
+    uint32_t math_mode = RD_MATH_STRICT;
     // scratch
     hipStream_t stream = nullptr;
     void *out_buf = nullptr; size_t out_cap = 0;
@@ -332,6 +337,15 @@ extern "C" int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t bl)
     return RD_OK;
 }
 
+extern "C" int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t mode)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->math_mode = mode;
+    return RD_OK;
+}
+
 extern "C" int rd_update_uniforms_with_zoom(rd_pipeline *p, const rd_edit_params *params, float zoom, float pan_x,
                                             float pan_y)
 {
@@ -355,13 +369,13 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
     if ((uintptr_t)dst_dev % rd_align_for(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "dst is not %zu-byte aligned", rd_align_for(fmt));
     const uint32_t W = p->info.width, H = p->info.height;
-    const rd_ku u = rd_make_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level);
+    const rd_ku u = rd_make_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode);
     const bool quads = tw == W && th == H && p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f &&
                        (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
                        !getenv("RD_FORCE_MAP");
     uint32_t blocks = 0;
     int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
-                               hist_dev != nullptr, p->slab32, nullptr, 0, s, &blocks);
+                               hist_dev != nullptr, p->math_mode, p->slab32, nullptr, 0, s, &blocks);
     if (rc) return rc;
     if (hist_dev) {
         hipLaunchKernelGGL(rd_reduce_slab32, dim3(3), dim3(256), 0, s, p->slab32, blocks, hist_dev);
@@ -457,6 +471,7 @@ struct rd_batch {
     uint32_t w = 0, h = 0, fmt = 0;
     bool hist = false;
     bool identity_ok = false;
+    uint32_t math_mode = RD_MATH_STRICT;
     rd_launch_cfg cfg;
     uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
     unsigned long long *slab64 = nullptr;      // blocks x 768
@@ -504,6 +519,14 @@ extern "C" void rd_batch_destroy(rd_batch *b)
     delete b;
 }
 
+extern "C" int rd_batch_set_math_mode(rd_batch *b, uint32_t mode)
+{
+    if (!b) return rd_fail(RD_ERR_INVALID_ARG, "NULL batch");
+    if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
+    b->math_mode = mode;
+    return RD_OK;
+}
+
 extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, uint32_t row_bands, void *stream)
 {
     if (!b || (!frames && n)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
@@ -517,12 +540,14 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
         if (!fr.cfa_dev || !fr.out_dev) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f);
         if ((uintptr_t)fr.cfa_dev % 4u) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f);
         if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f);
-        const rd_ku u = rd_make_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level);
+        const rd_ku u = rd_make_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level,
+                                   b->math_mode);
         for (uint32_t k = 0; k < bands; ++k) {
             const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
             const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
             int rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0,
-                                       u1, b->hist, nullptr, b->slab64, b->blocks, (hipStream_t)stream, nullptr);
+                                       u1, b->hist, b->math_mode, nullptr, b->slab64, b->blocks, (hipStream_t)stream,
+                                       nullptr);
             if (rc) return rc;
         }
     }

@@ -25,7 +25,9 @@
 
 #define RD_BLOCK 1024       // 16 waves: one workgroup per CU, 4 waves per SIMD
 #define RD_MAX_BLOCKS 1024  // slab capacity (workgroups per launch)
-#define RD_HK 32            // histogram copies per bin = LDS banks: lane l adds into copy l%32
+#ifndef RD_HK
+#define RD_HK 8             // private histogram copies per bin: lane l adds into copy l % RD_HK
+#endif
 
 typedef float rd_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rd_u2 __attribute__((ext_vector_type(2)));
@@ -94,6 +96,54 @@ __device__ __forceinline__ rd_rgb rd_colour(const rd_ku &u, float r, float g, fl
     return o;
 }
 
+// RD_MATH_CONTRACTED: the same shader text with every a*b+c contracted to one fma and the levels
+// division done as x*RN(1/d) -- the lowering an AMD shader compiler applies to the reference's WGSL
+// (oracle: colour_stack_contracted).  ~62 VALU + 3 pow instead of ~105 + 3 pow.
+__device__ __forceinline__ float rd_dot709_c(float r, float g, float b)
+{
+    return __builtin_fmaf(b, 0.0722f, __builtin_fmaf(g, 0.7152f, r * 0.2126f));
+}
+
+__device__ __forceinline__ rd_rgb rd_colour_c(const rd_ku &u, float r, float g, float b)
+{
+    r = r * u.wb_r; g = g * u.wb_g; b = b * u.wb_b;                    // :195
+    r = r * u.kr; b = b * u.kb; g = g * u.kg;                          // :200-205
+    float x = __builtin_fmaf(u.m[6], b, __builtin_fmaf(u.m[3], g, u.m[0] * r));   // :209-214 (columns)
+    float y = __builtin_fmaf(u.m[7], b, __builtin_fmaf(u.m[4], g, u.m[1] * r));
+    float z = __builtin_fmaf(u.m[8], b, __builtin_fmaf(u.m[5], g, u.m[2] * r));
+    r = x * u.em; g = y * u.em; b = z * u.em;                          // :217-218
+    float L = rd_dot709_c(r, g, b);                                    // :222
+    float hl = __builtin_fmaf(L, u.highlights, 1.0f);                  // :226
+    r = r * hl; g = g * hl; b = b * hl;
+    float sh = __builtin_fmaf(1.0f - L, u.shadows, 1.0f);              // :230
+    r = r * sh; g = g * sh; b = b * sh;
+    r = __builtin_fmaf(r - 0.5f, u.cf, 0.5f);                          // :233-234
+    g = __builtin_fmaf(g - 0.5f, u.cf, 0.5f);
+    b = __builtin_fmaf(b - 0.5f, u.cf, 0.5f);
+    r = (r - u.blacks) * u.rden;                                       // :239
+    g = (g - u.blacks) * u.rden;
+    b = (b - u.blacks) * u.rden;
+    float Y = rd_dot709_c(r, g, b);                                    // :243
+    float ys = Y * u.oms;                                              // :247
+    r = __builtin_fmaf(r, u.s, ys); g = __builtin_fmaf(g, u.s, ys); b = __builtin_fmaf(b, u.s, ys);
+    float sat = __builtin_fmaxf(r, __builtin_fmaxf(g, b)) - __builtin_fminf(r, __builtin_fminf(g, b)); // :251
+    float a2 = __builtin_fmaf(u.vibrance, 1.0f - sat, 1.0f);           // :254, :257
+    float Y2 = rd_dot709_c(r, g, b);                                   // :256
+    float yv = Y2 * (1.0f - a2);
+    r = __builtin_fmaf(r, a2, yv); g = __builtin_fmaf(g, a2, yv); b = __builtin_fmaf(b, a2, yv);
+    rd_rgb o;                                                          // :261-264
+    o.r = rd_gamma_clamp(r);
+    o.g = rd_gamma_clamp(g);
+    o.b = rd_gamma_clamp(b);
+    return o;
+}
+
+template <int MATH>
+__device__ __forceinline__ rd_rgb rd_colour_m(const rd_ku &u, float r, float g, float b)
+{
+    return MATH == RD_MATH_CONTRACTED ? rd_colour_c(u, r, g, b) : rd_colour(u, r, g, b);
+}
+
 // f32(raw)/4096 (shaders.rs:106-110, :167-168) with the optional integer black level.
 __device__ __forceinline__ float rd_norm(uint32_t raw, uint32_t bl)
 {
@@ -105,10 +155,13 @@ __device__ __forceinline__ float rd_norm(uint32_t raw, uint32_t bl)
 __device__ __forceinline__ uint32_t rd_q8(float x) { return (uint32_t)(x * 255.0f + 0.5f); }
 
 // ---------------------------------------------------------------------------------------------
-// Histogram: RD_HK private copies of every bin in LDS, copy = lane % RD_HK, so the 32 lanes of a
-// ds_add_u32 lane group always hit 32 different banks whatever the image content (a flat frame
-// would otherwise serialise 64-deep on one address).  Flushed once per workgroup, WITHOUT global
-// atomics, into that workgroup's slab row.
+// Histogram: RD_HK private copies of every bin in LDS, copy = lane % RD_HK, so a flat frame (all 64
+// lanes in one bin) serialises 64/RD_HK-deep on an address instead of 64-deep.  RD_HK = 8 keeps the
+// table at 24 KiB, which together with the 48 KiB store-transpose stage lets TWO 1024-thread
+// workgroups share a CU (32 waves); measured on a constant frame it costs nothing (LDS atomics are
+// ~5 cycles per wave-instruction and far from the bottleneck), RD_HK = 32 (96 KiB, one workgroup per
+// CU) was 10 % slower overall.  Flushed once per workgroup, WITHOUT global atomics, into that
+// workgroup's slab row.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rd_hist_zero(uint32_t *lh)
 {
@@ -187,7 +240,7 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 #include RD_COLOUR_HOOK_HEADER
 #endif
 #ifndef RD_COLOUR
-#define RD_COLOUR rd_colour
+#define RD_COLOUR rd_colour_m<MATH>
 #endif
 
 // FULL = every tile is a whole 64 quads (W % 128 == 0, true for 6016 and 11648): no lane masks, so
@@ -205,7 +258,7 @@ template <> struct rd_tile_out<RD_FMT_RGBA_F32> { rd_rgb c1, c2, c3; };
 template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
 template <> struct rd_tile_out<RD_FMT_RGBA_U8> { uint32_t v1, v2, v3; };
 
-template <int FMT, bool HIST, bool FULL, bool BURST = false>
+template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
 __global__ void __launch_bounds__(RD_BLOCK)
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                  uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t step_units,
@@ -325,7 +378,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
 
     if (tile < ntiles) {
         if (BURST) {
-            // ---- phase 0 (OFF by default; kept for A/B): read-only burst.  HBM3E serves this kernel's 1:8 read:write mix badly when
+            // ---- phase 0 (f32 surface only: the other surfaces are VALU-bound and gain nothing): read-only burst.  HBM3E serves this kernel's 1:8 read:write mix badly when
             // 256-B reads are sprinkled between the write streams: every isolated read costs the DRAM
             // channel a write->read->write turnaround (measured: the same bytes take 85-88 us mixed but
             // 65 us when the CFA plane is already in the Infinity Cache).  So every wave first touches
@@ -399,7 +452,7 @@ __device__ __forceinline__ float rd_tap(const uint16_t *cfa, int32_t W, int32_t 
     return rd_norm(cfa[(size_t)y * (size_t)W + (size_t)x], bl);
 }
 
-template <int FMT, bool HIST>
+template <int FMT, bool HIST, int MATH = RD_MATH_STRICT>
 __global__ void __launch_bounds__(RD_BLOCK)
 rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                uint32_t tw, uint32_t th, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
@@ -432,7 +485,7 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
                 if (even_col) { r = n; g = rd_tap(cfa, W, H, px + 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
                 else          { g = n; r = rd_tap(cfa, W, H, px - 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
             }
-            c = rd_colour(u, r, g, b);
+            c = rd_colour_m<MATH>(u, r, g, b);
         }
         uint32_t qr = 0, qg = 0, qb = 0;
         if (HIST || FMT == RD_FMT_RGBA_U8) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }

@@ -27,13 +27,20 @@ struct rd_ku {
 };
 
 static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const float cm[9],
-                               float zoom, float pan_x, float pan_y, uint32_t black_level)
+                               float zoom, float pan_x, float pan_y, uint32_t black_level,
+                               uint32_t math_mode = RD_MATH_STRICT)
 {
     rd_ku u;
     u.wb_r = wb[0]; u.wb_g = wb[1]; u.wb_b = wb[2];
-    u.kr = 1.0f + p.temperature * 0.3f;
-    u.kb = 1.0f - p.temperature * 0.3f;
-    u.kg = 1.0f + p.tint * 0.3f;
+    if (math_mode == RD_MATH_CONTRACTED) {           // a*b+c of the shader text -> one fma
+        u.kr = __builtin_fmaf(p.temperature, 0.3f, 1.0f);
+        u.kb = __builtin_fmaf(-p.temperature, 0.3f, 1.0f);
+        u.kg = __builtin_fmaf(p.tint, 0.3f, 1.0f);
+    } else {
+        u.kr = 1.0f + p.temperature * 0.3f;
+        u.kb = 1.0f - p.temperature * 0.3f;
+        u.kg = 1.0f + p.tint * 0.3f;
+    }
     for (int i = 0; i < 9; ++i) u.m[i] = cm[i];
     // pow(2.0, e) = exp2(e * log2(2.0)), log2(2.0) == 1 exactly in the pinned pair.
     u.em = rd_exp2f(p.exposure * rd_log2f(2.0f));

@@ -77,6 +77,10 @@ class RenderPipeline:
     def set_black_level(self, black_level: int) -> None:
         check(_lib.lib().rd_pipeline_set_black_level(self._h, int(black_level)))
 
+    def set_math_mode(self, math_mode: int) -> None:
+        """MATH_STRICT (default, literal WGSL order) or MATH_CONTRACTED (fma + reciprocal multiply)."""
+        check(_lib.lib().rd_pipeline_set_math_mode(self._h, int(math_mode)))
+
     # -- renders ----------------------------------------------------------------------------------
     def _bytes(self, fn, w: int, h: int) -> np.ndarray:
         out = np.empty(w * h * 4, np.uint8)

@@ -9,7 +9,7 @@ from tests.helpers import CM_TEST, WB_DAYLIGHT, random_cfa, random_params
 pytestmark = pytest.mark.gpu
 
 
-def _run_batch(ra, refc, h, w, n, fmt, bands, with_hist=True):
+def _run_batch(ra, refc, h, w, n, fmt, bands, with_hist=True, math=0):
     rng = np.random.default_rng([0x52415745, h, w, n])
     cfas = [random_cfa(rng, h, w) for _ in range(n)]
     params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
@@ -17,12 +17,12 @@ def _run_batch(ra, refc, h, w, n, fmt, bands, with_hist=True):
     d_in = [DevBuf.from_array(c) for c in cfas]
     d_out = [DevBuf(h * w * bpp) for _ in range(n)]
     d_hist = DevBuf(768 * 8)
-    be = ra.BatchExporter(0, w, h, fmt, with_hist)
+    be = ra.BatchExporter(0, w, h, fmt, with_hist, math_mode=math)
     frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
     exp_hist = np.zeros(768, np.uint64)
     exps = []
     for c, p in zip(cfas, params):
-        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST, math_mode=math)
         e = refc.render_f32(c, u)
         exps.append(e)
         exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
@@ -73,6 +73,12 @@ def test_batch_mid_size_frames(gpu_lib, refc):
     ra = gpu_lib
     _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F32, 1)
     _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F16, 4)
+
+
+def test_batch_contracted_math(gpu_lib, refc):
+    ra = gpu_lib
+    _run_batch(ra, refc, 34, 256, 3, ra.FMT_RGBA_F32, 2, math=ra.MATH_CONTRACTED)
+    _run_batch(ra, refc, 34, 48, 3, ra.FMT_RGBA_U8, 1, math=ra.MATH_CONTRACTED)
 
 
 def test_batch_rejects_bad_arguments(gpu_lib):

@@ -19,7 +19,8 @@ F = np.float32
 ULP_TOL = 1   # north_star: "<= 1 ULP fp32 per channel"
 
 
-def make_pipe(ra, cfa, params=None, wb=(1, 1, 1, 1), cm=CM_IDENTITY, zoom=None, pan=(0.0, 0.0), bl=0, image_id=7):
+def make_pipe(ra, cfa, params=None, wb=(1, 1, 1, 1), cm=CM_IDENTITY, zoom=None, pan=(0.0, 0.0), bl=0, image_id=7,
+              math=0):
     h, w = cfa.shape
     ep = ra.EditParams(**(params or {}))
     p = ra.RenderPipeline.new(image_id, cfa.reshape(-1), w, h, ep, wb, cm)
@@ -27,11 +28,14 @@ def make_pipe(ra, cfa, params=None, wb=(1, 1, 1, 1), cm=CM_IDENTITY, zoom=None, 
         p.update_uniforms_with_zoom(ep, zoom, pan[0], pan[1])
     if bl:
         p.set_black_level(bl)
+    if math:
+        p.set_math_mode(math)
     return p
 
 
-def oracle(refc, cfa, params=None, wb=(1, 1, 1, 1), cm=CM_IDENTITY, tw=None, th=None, zoom=1.0, pan=(0.0, 0.0), bl=0):
-    u = refc.make_uniforms(params, wb, cm, zoom, pan[0], pan[1], bl)
+def oracle(refc, cfa, params=None, wb=(1, 1, 1, 1), cm=CM_IDENTITY, tw=None, th=None, zoom=1.0, pan=(0.0, 0.0), bl=0,
+           math=0):
+    u = refc.make_uniforms(params, wb, cm, zoom, pan[0], pan[1], bl, math)
     return refc.render_f32(cfa, u, tw, th, nthreads=8)
 
 
@@ -136,17 +140,42 @@ def test_kat_matrix_transpose_and_negative_gamma(gpu_lib, refc):
 SIZES = [(2, 2), (2, 4), (3, 5), (16, 24), (17, 24), (16, 25), (31, 33), (64, 96), (130, 258), (257, 514), (1, 64), (64, 2)]
 
 
+@pytest.mark.parametrize("math", [0, 1], ids=["strict", "contracted"])
 @pytest.mark.parametrize("h,w", SIZES)
-def test_random_parity(gpu_lib, refc, h, w):
+def test_random_parity(gpu_lib, refc, h, w, math):
     ra = gpu_lib
     rng = np.random.default_rng([0x52415745, h, w])
     for trial in range(4):
         cfa = random_cfa(rng, h, w, 65536 if trial == 3 else 4096)
         params = random_params(rng) if trial else None
         cm = CM_TEST if trial % 2 else CM_IDENTITY
-        pipe = make_pipe(ra, cfa, params, WB_DAYLIGHT, cm)
-        check_all_surfaces(ra, refc, pipe, oracle(refc, cfa, params, WB_DAYLIGHT, cm))
+        pipe = make_pipe(ra, cfa, params, WB_DAYLIGHT, cm, math=math)
+        check_all_surfaces(ra, refc, pipe, oracle(refc, cfa, params, WB_DAYLIGHT, cm, math=math))
+        with force_map():                     # the general kernel in the same arithmetic
+            got = pipe.render()
+        assert np.array_equal(got.view(np.uint32), oracle(refc, cfa, params, WB_DAYLIGHT, cm, math=math).view(np.uint32))
         pipe.close()
+
+
+def test_contracted_mode_edges_and_preview(gpu_lib, refc):
+    """RD_MATH_CONTRACTED: range ends, degenerate stacks, zoom/pan map, 128 x 128k tiles (W % 128 == 0)."""
+    ra = gpu_lib
+    rng = np.random.default_rng(77)
+    cfa = random_cfa(rng, 40, 256)
+    for name, (lo, hi) in UI_RANGES.items():
+        for v in (lo, hi):
+            p = {name: float(F(v))}
+            pipe = make_pipe(ra, cfa, p, WB_DAYLIGHT, CM_TEST, math=1)
+            assert np.array_equal(pipe.render().view(np.uint32), oracle(refc, cfa, p, WB_DAYLIGHT, CM_TEST, math=1).view(np.uint32))
+    for p in ({"exposure": 200.0}, {"whites": 0.0, "blacks": 0.0001}, {"whites": 0.2, "blacks": 0.2}, {"contrast": 500.0}):
+        pipe = make_pipe(ra, cfa, p, WB_DAYLIGHT, CM_TEST, math=1)
+        got = pipe.render()
+        assert not np.isnan(got).any()
+        assert np.array_equal(got.view(np.uint32), oracle(refc, cfa, p, WB_DAYLIGHT, CM_TEST, math=1).view(np.uint32))
+    p = random_params(rng)
+    pipe = make_pipe(ra, cfa, p, WB_DAYLIGHT, CM_TEST, zoom=1.7, pan=(0.05, -0.1), math=1)
+    exp = oracle(refc, cfa, p, WB_DAYLIGHT, CM_TEST, tw=100, th=30, zoom=1.7, pan=(0.05, -0.1), math=1)
+    check_all_surfaces(ra, refc, pipe, exp, 100, 30)
 
 
 @pytest.mark.parametrize("name", list(UI_RANGES))
@@ -167,6 +196,7 @@ def test_out_of_range_and_degenerate_params(gpu_lib, refc):
     stacks = [
         ({"exposure": 20.0}, WB_DAYLIGHT), ({"exposure": -40.0}, WB_DAYLIGHT), ({"exposure": 200.0}, WB_DAYLIGHT),
         ({"whites": 0.2, "blacks": 0.2}, WB_DAYLIGHT), ({"whites": 0.0, "blacks": 0.5}, WB_DAYLIGHT),
+        ({"whites": 0.0, "blacks": 0.0001}, WB_DAYLIGHT),          # denominator exactly 0: generic divide path
         ({"saturation": -100.0, "vibrance": 1.0}, WB_DAYLIGHT), ({"contrast": 500.0}, WB_DAYLIGHT),
         ({"temperature": 5.0, "tint": -5.0}, WB_DAYLIGHT), ({}, (-1.0, 1.0, 1e-38, 1.0)), ({}, (1e-42, 1e30, 0.0, 1.0)),
         ({"highlights": 50.0, "shadows": -50.0}, WB_DAYLIGHT),

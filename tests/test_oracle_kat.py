@@ -199,3 +199,28 @@ def test_pinned_pow_close_to_libm(refc):
         b = c_render(refc, cfa, p, WB_DAYLIGHT, CM_TEST, pow_mode=1)
         d = np.abs(refc.pack_u8(a).astype(int) - refc.pack_u8(b).astype(int))
         assert d.max() <= 1
+
+
+# ---- the contracted arithmetic (RD_MATH_CONTRACTED): twins agree bit for bit; vs strict <= 1 LSB at 8 bits ----
+def test_contracted_mode_twins_and_deviation(refc, rng):
+    worst_abs, worst_lsb = 0.0, 0
+    for trial in range(12):
+        cfa = random_cfa(rng, 24, 32, 4096 if trial % 3 else 65536)
+        p = random_params(rng) if trial else {}
+        cm = CM_TEST if trial % 2 else CM_IDENTITY
+        uc = refc.make_uniforms(p, WB_DAYLIGHT, cm, math_mode=refc.MATH_CONTRACTED)
+        a = refc.render_f32(cfa, uc)
+        b = dn.render_f32(cfa, dn.Uniforms(**p, wb=WB_DAYLIGHT, cm=tuple(cm), math_mode="contracted"))
+        assert ulp_diff(a, b) == 0
+        s = refc.render_f32(cfa, refc.make_uniforms(p, WB_DAYLIGHT, cm))
+        worst_abs = max(worst_abs, float(np.abs(a - s).max()))
+        worst_lsb = max(worst_lsb, int(np.abs(refc.pack_u8(a).astype(int) - refc.pack_u8(s).astype(int)).max()))
+    assert worst_lsb <= 1            # what the reference stores (Rgba8Unorm) moves by at most one code
+    assert worst_abs < 5e-4          # f32 surface: cancellation (contrast, levels) amplifies the last-bit differences
+
+
+def test_contracted_default_stack_is_still_the_identity_chain(refc):
+    """With default sliders every contracted step is exact too: K1 holds in both modes."""
+    cfa = np.full((4, 4), 2048, np.uint16)
+    a = refc.render_f32(cfa, refc.make_uniforms(None, math_mode=refc.MATH_CONTRACTED))
+    assert np.all(refc.pack_u8(a)[..., :3] == 186)

@@ -198,6 +198,35 @@ __global__ void __launch_bounds__(1024) mb_mix(const uint32_t *__restrict__ in, 
     }
 }
 
+// same 1:8 mix, but D loads in flight per wave (register ring, fully unrolled): is the read penalty latency?
+template <int D>
+__global__ void __launch_bounds__(1024) mb_mix_deep(const uint32_t *__restrict__ in, float *__restrict__ out, size_t in_dwords)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t wave = (size_t)blockIdx.x * 16u + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 16u;
+    const size_t nchunks = in_dwords / 64;                      // 256 B per wave-chunk, 2 KiB written
+    rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
+    uint32_t ring[D];
+    size_t c = wave;
+#pragma unroll
+    for (int k = 0; k < D; ++k) { size_t cc = c + k * nwaves; ring[k] = in[(cc < nchunks ? cc : wave) * 64 + lane]; }
+    while (c < nchunks) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (c < nchunks) {
+                const uint32_t cur = ring[k];
+                size_t nn = c + (size_t)D * nwaves;
+                ring[k] = in[(nn < nchunks ? nn : wave) * 64 + lane];
+                const float f = (float)(cur & 0xfffu) * (1.0f / 4096.0f);
+                const rd_f4 val = { f, f, f, 1.0f };
+                __builtin_nontemporal_store(val, o + (c * 2) * 64u + lane);
+                __builtin_nontemporal_store(val, o + (c * 2 + 1) * 64u + lane);
+                c += nwaves;
+            }
+        }
+    }
+}
+
 typedef float rd_f2 __attribute__((ext_vector_type(2)));
 // ---- VALU calibration: ITER x 16 independent ops per lane -----------------------------------------
 template <int KIND>
@@ -238,7 +267,8 @@ int main(int argc, char **argv)
     std::vector<uint16_t> host((size_t)W * H);
     for (int i = 0; i < NIN; ++i) {
         uint64_t s = 0x52415745ull + i;
-        for (auto &v : host) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (uint16_t)((s >> 40) & 4095u); }
+        const bool flat = getenv("MB_FLAT") != nullptr;     // constant frame: worst case for histogram contention
+        for (auto &v : host) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = flat ? (uint16_t)2048 : (uint16_t)((s >> 40) & 4095u); }
         CK(hipMalloc((void **)&din[i], in_bytes)); CK(hipMemcpy(din[i], host.data(), in_bytes, hipMemcpyHostToDevice));
     }
     for (int i = 0; i < NOUT; ++i) CK(hipMalloc((void **)&dout[i], out_bytes));
@@ -248,7 +278,10 @@ int main(int argc, char **argv)
     p.vibrance = 0.3f; p.saturation = 20.0f; p.temperature = 0.2f; p.tint = -0.1f;
     const float wb[4] = { 2.0f, 1.0f, 1.5f, 1.0f };
     const float cm[9] = { 1.6f, -0.4f, -0.2f, -0.3f, 1.5f, -0.2f, 0.0f, -0.5f, 1.5f };
-    rd_ku u = rd_make_ku(p, wb, cm, 1.0f, 0.0f, 0.0f, 0);
+#ifndef MATHMODE
+#define MATHMODE 0
+#endif
+    rd_ku u = rd_make_ku(p, wb, cm, 1.0f, 0.0f, 0.0f, 0, MATHMODE);
     const uint32_t qpr = W / 2;
     hipStream_t s; CK(hipStreamCreate(&s));
 
@@ -281,13 +314,18 @@ int main(int argc, char **argv)
     ADD("store+hist nt 1024x256", M_STORE | M_HIST, 1024, 256);
     unsigned long long *slab64; CK(hipMalloc((void **)&slab64, (size_t)RD_MAX_BLOCKS * 768 * 8)); CK(hipMemset(slab64, 0, (size_t)RD_MAX_BLOCKS * 768 * 8));
     const uint32_t tpu = (qpr + 63) / 64;
+#ifndef MATHMODE
+#define MATHMODE 0
+#endif
 #define PROD(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                   \
     vs.push_back({ NAME, [&, qpr, tpu](int k) { const uint32_t nw = (BLOCKS) * RD_WAVES;               \
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
                            W, H, 0u, H / 2 + 1, tpu, nw / tpu, nw % tpu, u, S32, S64); }, {} })
     PROD("PRODUCT f32 hist slab32 x256", 0, true, 256, false, slab, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 hist slab64 x256", 0, true, 256, false, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f32 hist slab64 x256 BURST", 0, true, 256, true, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f32 hist slab64 x512", 0, true, 512, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f32 hist slab64 x512 BURST", 0, true, 512, true, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f32 nohist x256", 0, false, 256, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 nohist x512", 0, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 nohist x512 BURST", 0, false, 512, true, (uint32_t *)nullptr, (unsigned long long *)nullptr);
@@ -313,6 +351,13 @@ int main(int argc, char **argv)
     MIX("mix 1:8 load16B noprefetch x512", 16, false, 512);
     MIX("mix 1:8 load16B prefetch x2048", 16, true, 2048);
     MIX("mix 1:8 load4B prefetch x2048", 4, true, 2048);
+#define MIXD(NAME, D, BLOCKS) vs.push_back({ NAME, [&](int k) { hipLaunchKernelGGL((mb_mix_deep<D>), dim3(BLOCKS), dim3(1024), 0, s, (const uint32_t *)din[k % NIN], dout[k % NOUT], in_bytes / 4); }, {} })
+    MIXD("mixdeep D=1 load4B x512", 1, 512);
+    MIXD("mixdeep D=2 load4B x512", 2, 512);
+    MIXD("mixdeep D=4 load4B x512", 4, 512);
+    MIXD("mixdeep D=8 load4B x512", 8, 512);
+    MIXD("mixdeep D=4 load4B x256", 4, 256);
+    MIXD("mixdeep D=8 load4B x256", 8, 256);
     MIX("mix 1:8 load64B prefetch x512", 64, true, 512);
     MIX("mix 1:8 load64B prefetch x2048", 64, true, 2048);
     MIX("mix 1:8 load256B prefetch x512", 256, true, 512);
