@@ -149,11 +149,16 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
 {
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
     const uint32_t nwaves = blocks * RD_WAVES;
-    if (W % 128u == 0)
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+    static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;   // A/B override: 0 / 1
+    const bool burst = burst_env < 0 ? (FMT == RD_FMT_RGBA_F32) : burst_env != 0;
+    if (W % 128u == 0 && burst)
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+                           unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+    else if (W % 128u == 0)
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
                            unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
     else
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false, MATH>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
                            unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
 }
 
@@ -378,7 +383,7 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
                                hist_dev != nullptr, p->math_mode, p->slab32, nullptr, 0, s, &blocks);
     if (rc) return rc;
     if (hist_dev) {
-        hipLaunchKernelGGL(rd_reduce_slab32, dim3(3), dim3(256), 0, s, p->slab32, blocks, hist_dev);
+        hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, s, p->slab32, blocks, hist_dev);
         RD_HIP(hipGetLastError());
     }
     return RD_OK;
@@ -456,7 +461,7 @@ extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_
     const uint32_t blocks = rd_blocks_for(p->cfg, npx, true);
     hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, p->stream, (const uint32_t *)p->out_buf,
                        (uint32_t)npx, p->slab32);
-    hipLaunchKernelGGL(rd_reduce_slab32, dim3(3), dim3(256), 0, p->stream, p->slab32, blocks, p->hist_dev);
+    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, p->stream, p->slab32, blocks, p->hist_dev);
     RD_HIP(hipGetLastError());
     RD_HIP(hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
     RD_HIP(hipStreamSynchronize(p->stream));
@@ -560,7 +565,7 @@ extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
     if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
-    hipLaunchKernelGGL(rd_reduce_slab64, dim3(3), dim3(256), 0, (hipStream_t)stream, b->slab64, b->blocks,
+    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(256), 0, (hipStream_t)stream, b->slab64, b->blocks,
                        (unsigned long long *)hist_dev);
     RD_HIP(hipGetLastError());
     return RD_OK;

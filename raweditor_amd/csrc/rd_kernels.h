@@ -510,27 +510,41 @@ rd_hist_u8(const uint32_t *__restrict__ rgba, uint32_t npx, uint32_t *slab32)
     rd_hist_flush(lh, slab32, nullptr);
 }
 
-// out32[bin] = sum over workgroups of slab32[wg][bin]   (launch: 3 x 256 threads)
-__global__ void rd_reduce_slab32(const uint32_t *__restrict__ slab32, uint32_t nblocks,
-                                 uint32_t *__restrict__ out32)
+// Fold the per-workgroup slab rows: block b owns bins [32b, 32b+32), thread (g, j) sums rows g, g+8, ...
+// of bin 32b+j; the 8 partial sums per bin meet in LDS.  Launch: 24 blocks x 256 threads.
+template <typename T>
+__device__ __forceinline__ T rd_fold_bins(T *__restrict__ slab, uint32_t nblocks, bool clear)
 {
-    const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= 768u) return;
-    uint32_t sum = 0;
-    for (uint32_t w = 0; w < nblocks; ++w) sum += slab32[(size_t)w * 768u + bin];
-    out32[bin] = sum;
+    __shared__ T part[8][32];
+    const uint32_t j = threadIdx.x & 31u, g = threadIdx.x >> 5;
+    const uint32_t bin = blockIdx.x * 32u + j;
+    T sum = 0;
+    for (uint32_t w = g; w < nblocks; w += 8u) {
+        sum += slab[(size_t)w * 768u + bin];
+        if (clear) slab[(size_t)w * 768u + bin] = 0;
+    }
+    part[g][j] = sum;
+    __syncthreads();
+    T tot = 0;
+    if (g == 0) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) tot += part[k][j];
+    }
+    return tot;
+}
+
+// out32[bin] = sum over workgroups of slab32[wg][bin]
+__global__ void __launch_bounds__(256) rd_reduce_slab32(uint32_t *__restrict__ slab32, uint32_t nblocks,
+                                                        uint32_t *__restrict__ out32)
+{
+    const uint32_t tot = rd_fold_bins<uint32_t>(slab32, nblocks, false);
+    if (threadIdx.x < 32u) out32[blockIdx.x * 32u + threadIdx.x] = tot;
 }
 
 // out64[bin] = sum over workgroups of slab64[wg][bin]; the slab is zeroed for the next batch.
-__global__ void rd_reduce_slab64(unsigned long long *__restrict__ slab64, uint32_t nblocks,
-                                 unsigned long long *__restrict__ out64)
+__global__ void __launch_bounds__(256) rd_reduce_slab64(unsigned long long *__restrict__ slab64, uint32_t nblocks,
+                                                        unsigned long long *__restrict__ out64)
 {
-    const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= 768u) return;
-    unsigned long long sum = 0;
-    for (uint32_t w = 0; w < nblocks; ++w) {
-        sum += slab64[(size_t)w * 768u + bin];
-        slab64[(size_t)w * 768u + bin] = 0ull;
-    }
-    out64[bin] = sum;
+    const unsigned long long tot = rd_fold_bins<unsigned long long>(slab64, nblocks, true);
+    if (threadIdx.x < 32u) out64[blockIdx.x * 32u + threadIdx.x] = tot;
 }
