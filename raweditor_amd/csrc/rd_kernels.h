@@ -275,7 +275,10 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
     const uint32_t ntiles = (unit1 - unit0) * tpu;               // < 2^32: checked on the host
     const uint32_t nwaves = gridDim.x * RD_WAVES;                // == step_units*tpu + step_rem
     const uint32_t copy = lane & (RD_HK - 1);
-    uint32_t tile = blockIdx.x * RD_WAVES + wave;
+    // Wave -> slot is block-cyclic (slot = wave_in_block * gridDim + block): in the last, partial round of
+    // tiles the busy slots are then spread evenly over all workgroups, i.e. over all CUs.  With the
+    // block-major order the first 53 % of the workgroups got one tile more per wave (+4 % on the heaviest CU).
+    uint32_t tile = wave * gridDim.x + blockIdx.x;
     uint32_t unit = unit0 + tile / tpu;
     uint32_t qt = tile % tpu;
 
@@ -386,20 +389,23 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             // in this phase together (persistent grid, nothing stored yet), the 48 MB land in the 256 MiB
             // Infinity Cache in one pure-read burst, and the main loop's loads are served on-die.
             // nt stores do not displace them (measured).
-            uint32_t t = tile, pu = unit, pq = qt, sink = 0;
-            while (t < ntiles) {
-                uint32_t v[8];
+            // The sweep need not follow the tile ownership: any wave may pull any line into the (shared)
+            // Infinity Cache, so it is a plain coalesced pass over this launch's rows, 16 B per lane.
+            typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
+            const uint32_t row_lo = unit0 ? 2u * unit0 - 1u : 0u;
+            const uint32_t row_hi = 2u * (unit1 - 1u) < H ? 2u * (unit1 - 1u) + 1u : H;       // exclusive
+            const rd_u4 *src = reinterpret_cast<const rd_u4 *>(cfa + (size_t)row_lo * W);
+            const size_t n16 = ((size_t)(row_hi - row_lo) * W * sizeof(uint16_t)) / 16u;       // whole 16-B chunks
+            const size_t gw = (size_t)(blockIdx.x * RD_WAVES + wave) * 64u + lane, gstride = (size_t)nwaves * 64u;
+            uint32_t sink = 0;
+            if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+                for (size_t i0 = gw; i0 < n16; i0 += 4 * gstride) {
+                    rd_u4 v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool in = t < ntiles;                  // wave-uniform; past the end: re-touch the last tile
-                    load_tile(pu, pq, v[2 * k], v[2 * k + 1]);
-                    if (in) {
-                        t += nwaves;
-                        if (t < ntiles) { pu += step_units; pq += step_rem; if (pq >= tpu) { pq -= tpu; pu += 1u; } }
-                    }
+                    for (int k = 0; k < 4; ++k) { const size_t ii = i0 + k * gstride; v[k] = src[ii < n16 ? ii : gw]; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sink ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sink ^= v[k];
             }
             asm volatile("" ::"v"(sink));
         }
