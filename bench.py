@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--format", choices=["f32", "f16", "u8"], default="f32")
     ap.add_argument("--ring", type=int, default=8, help="output buffers cycled through")
     ap.add_argument("--row-bands", type=int, default=1)
+    ap.add_argument("--math", choices=["strict", "contracted"], default="strict",
+                    help="arithmetic of the colour stack (rd_math_mode); strict = literal WGSL order (default)")
+    ap.add_argument("--no-alt-math", action="store_true",
+                    help="skip the short extra run in the other math mode (reported under 'alt_math', N=1 only)")
     ap.add_argument("--no-hist", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
@@ -130,7 +134,8 @@ def main():
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    be = ra.BatchExporter(local_rank, W, H, fmt, with_hist)
+    math_mode = ra.MATH_CONTRACTED if args.math == "contracted" else ra.MATH_STRICT
+    be = ra.BatchExporter(local_rank, W, H, fmt, with_hist, math_mode=math_mode)
     frames = be.make_frames([c.data_ptr() for c in cfas], [ring[i % len(ring)].data_ptr() for i in range(F)],
                             params, WB, CM)
     stream = torch.cuda.Stream(device=dev)
@@ -198,9 +203,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[2]: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
-                        f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}",
+                        f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}, "
+                        f"{args.math} f32 arithmetic",
             "frames_per_gpu": F, "width": W, "height": H, "surface": f"rgba_{args.format}",
-            "row_bands": args.row_bands, "out_ring": len(ring),
+            "row_bands": args.row_bands, "out_ring": len(ring), "math_mode": args.math,
             "parallelism": f"frames sharded round-robin over {world} GPU(s); RCCL all-reduce of i64[768] histogram only",
         },
         "roofline": {
@@ -210,6 +216,28 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes),
         },
     }
+    if world == 1 and not args.no_alt_math:
+        # Reported-only: the same workload in the other arithmetic, 5 steps.
+        other = "contracted" if args.math == "strict" else "strict"
+        be2 = ra.BatchExporter(local_rank, W, H, fmt, with_hist,
+                               math_mode=ra.MATH_CONTRACTED if other == "contracted" else ra.MATH_STRICT)
+        with torch.cuda.stream(stream):
+            be2.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(5):
+                be2.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
+                if with_hist:
+                    be2.histogram(hist.data_ptr(), stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (5 * F * max(1, args.row_bands))
+        ach = alg_bytes / (us * 1e-6) / 1e9
+        result["alt_math"] = {"math_mode": other, "value": round(W * H / max(1, args.row_bands) / us, 1), "unit": "MP/s",
+                              "launch_us": round(us, 2), "achieved_GBps": round(ach, 1),
+                              "frac": round(ach / HBM_PEAK_GBPS, 4)}
+        be2.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
     if rank == 0:

@@ -343,3 +343,39 @@ def test_full_size_24mp(gpu_lib, refc):
     with force_map():
         got_map = pipe.render(fmt=ra.FMT_RGBA_F32)
     assert np.array_equal(got_map.view(np.uint32), got.view(np.uint32))
+
+
+# ---- BASELINE config 5 shape: 100 MP frame (11648 x 8736), f16 surface, tiled multi-launch (row bands) ----
+def test_full_size_100mp_f16_row_bands(gpu_lib, refc):
+    """wgpu's 8192-px texture limit (pipeline.rs:164) would reject this frame; linear buffers do not care.
+    One pipeline render (single launch) and the batch path in 8 row bands must both match the oracle on
+    sampled bands (first / last rows, a band seam, the middle) and agree with each other everywhere."""
+    from tests.gpu_util import DevBuf, sync
+    ra = gpu_lib
+    h, w = 8736, 11648
+    rng = np.random.default_rng(100)
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST)
+    d_in = DevBuf.from_array(cfa)
+    d_out = DevBuf(h * w * 8)
+    d_hist = DevBuf(768 * 8)
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F16, True)
+    fr = be.make_frames([d_in.ptr], [d_out.ptr], [ra.EditParams(**params)], WB_DAYLIGHT, CM_TEST)
+    be.develop(fr, row_bands=8)
+    be.histogram(d_hist.ptr)
+    sync()
+    got = d_out.to_array(np.uint16, (h, w, 4))
+    units = h // 2 + 1
+    seam = 2 * (units * 3 // 8) - 1                      # first row of band 3
+    for r0, r1 in ((0, 4), (seam - 3, seam + 3), (h // 2, h // 2 + 4), (h - 4, h)):
+        exp = refc.pack_f16(refc.render_band(cfa, u, r0, r1)).view(np.uint16)
+        assert np.array_equal(got[r0:r1], exp), (r0, r1)
+    hist = d_hist.to_array(np.uint64, (768,))
+    assert int(hist.sum()) == 3 * h * w
+    be.develop(fr, row_bands=1)                          # one launch: same surface, same histogram
+    be.histogram(d_hist.ptr)
+    sync()
+    assert np.array_equal(d_out.to_array(np.uint16, (h, w, 4)), got)
+    assert np.array_equal(d_hist.to_array(np.uint64, (768,)), hist)
+    be.close()
