@@ -45,7 +45,9 @@ typedef enum rd_status {
 typedef enum rd_format {
     RD_FMT_RGBA_F32 = 0, /* 16 B/px */
     RD_FMT_RGBA_F16 = 1, /*  8 B/px, IEEE binary16, round-to-nearest-even of the f32 value */
-    RD_FMT_RGBA_U8 = 2   /*  4 B/px, trunc(x*255 + 0.5), alpha 255 */
+    RD_FMT_RGBA_U8 = 2,  /*  4 B/px, trunc(x*255 + 0.5), alpha 255 */
+    RD_FMT_RGB_U8 = 3    /*  3 B/px, the RGBA8 surface with alpha dropped: what the reference feeds its JPEG
+                             encoder (main.rs:1777-1786 strips alpha on the CPU) */
 } rd_format;
 
 /* Arithmetic of the colour stack.  Both are restatements of the same WGSL text
@@ -167,6 +169,24 @@ int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n_frames, uint3
 /* Reduce the accumulated histogram into `hist_dev` (768 x u64 on the device: R[256] G[256] B[256])
  * and reset the accumulator.  Enqueued on `stream`; the multi-GPU sum is the caller's all-reduce. */
 int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);
+
+/* ---- export feed (the step after the path) ----------------------------------- */
+/* The GPU half of export_image_async (main.rs:1744-1799) for a stream of frames: render_full_res_to_bytes'
+ * blocking map/copy (pipeline.rs:552-605, "1-2 s for 24 MP") becomes a ring of pinned host buffers filled by
+ * asynchronous D2H copies on a second stream, so the copy of frame i overlaps the kernel of frame i+1.
+ * `format` is normally RD_FMT_RGBA_U8 (PNG path, main.rs:1767-1775) or RD_FMT_RGB_U8 (JPEG path: the alpha strip
+ * of main.rs:1777-1786 is fused into the kernel and a quarter of the PCIe bytes disappears). */
+typedef struct rd_exporter rd_exporter;
+int rd_exporter_create(int device, uint32_t width, uint32_t height, uint32_t format, uint32_t math_mode,
+                       uint32_t n_slots, rd_exporter **out);
+void rd_exporter_destroy(rd_exporter *e);
+/* Enqueue one frame (frame->out_dev is ignored; zoom 1 / pan 0).  *slot receives the ring slot used.  Fails with
+ * RD_ERR_INVALID_ARG if that slot still holds an un-released frame. */
+int rd_exporter_submit(rd_exporter *e, const rd_frame *frame, uint32_t *slot);
+/* Block until the slot's surface is in host memory.  *data (pinned, width*height*bpp bytes, tightly packed) stays
+ * valid until rd_exporter_release(slot). */
+int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len);
+int rd_exporter_release(rd_exporter *e, uint32_t slot);
 
 /* ---- plumbing for hosts without a HIP binding (tests, the Python mirror) -------------------- */
 int rd_device_malloc(int device, size_t bytes, void **out);

@@ -9,9 +9,9 @@ import sys
 from .build import LIB_PATH
 
 RD_OK = 0
-FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8 = 0, 1, 2
+FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8, FMT_RGB_U8 = 0, 1, 2, 3
 MATH_STRICT, MATH_CONTRACTED = 0, 1
-BYTES_PER_PIXEL = {FMT_RGBA_F32: 16, FMT_RGBA_F16: 8, FMT_RGBA_U8: 4}
+BYTES_PER_PIXEL = {FMT_RGBA_F32: 16, FMT_RGBA_F16: 8, FMT_RGBA_U8: 4, FMT_RGB_U8: 3}
 
 
 class RawdevError(RuntimeError):
@@ -72,6 +72,11 @@ PROTOTYPES = {
     "rd_batch_set_math_mode": (_I, [_VP, _U32]),
     "rd_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32, _VP]),
     "rd_batch_histogram": (_I, [_VP, _VP, _VP]),
+    "rd_exporter_create": (_I, [_I, _U32, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),
+    "rd_exporter_destroy": (None, [_VP]),
+    "rd_exporter_submit": (_I, [_VP, C.POINTER(RdFrame), C.POINTER(_U32)]),
+    "rd_exporter_wait": (_I, [_VP, _U32, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rd_exporter_release": (_I, [_VP, _U32]),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_device_free": (_I, [_I, _VP]),
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),

@@ -80,7 +80,7 @@ extern "C" int rd_derived_dims(uint32_t w, uint32_t h, uint32_t *pw, uint32_t *p
 
 extern "C" size_t rd_format_bytes_per_pixel(uint32_t f)
 {
-    return f == RD_FMT_RGBA_F32 ? 16 : f == RD_FMT_RGBA_F16 ? 8 : f == RD_FMT_RGBA_U8 ? 4 : 0;
+    return f == RD_FMT_RGBA_F32 ? 16 : f == RD_FMT_RGBA_F16 ? 8 : f == RD_FMT_RGBA_U8 ? 4 : f == RD_FMT_RGB_U8 ? 3 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -185,6 +185,7 @@ static void rd_launch_map_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t
     do {                                                                                          \
         if (fmt == RD_FMT_RGBA_F32) RD_DISPATCH3(fn, RD_FMT_RGBA_F32, hist, math, __VA_ARGS__);   \
         else if (fmt == RD_FMT_RGBA_F16) RD_DISPATCH3(fn, RD_FMT_RGBA_F16, hist, math, __VA_ARGS__); \
+        else if (fmt == RD_FMT_RGB_U8) RD_DISPATCH3(fn, RD_FMT_RGB_U8, hist, math, __VA_ARGS__);  \
         else RD_DISPATCH3(fn, RD_FMT_RGBA_U8, hist, math, __VA_ARGS__);                           \
     } while (0)
 
@@ -197,7 +198,7 @@ static uint32_t rd_blocks_for(const rd_launch_cfg &cfg, uint64_t items, bool his
     return b ? (uint32_t)b : 1u;
 }
 
-static size_t rd_align_for(uint32_t) { return 16; }   // every surface is written with 8- or 16-byte vectors
+static size_t rd_align_for(uint32_t fmt) { return fmt == RD_FMT_RGB_U8 ? 4 : 16; }   // vector width of the surface stores
 
 // Enqueue one render of (cfa, W, H) to a tw x th target.  Returns the number of workgroups used
 // (the slab rows written) through *blocks_out.  use_quads selects the export kernel.
@@ -377,7 +378,7 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
     const rd_ku u = rd_make_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode);
     const bool quads = tw == W && th == H && p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f &&
                        (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
-                       !getenv("RD_FORCE_MAP");
+                       (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
     uint32_t blocks = 0;
     int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
                                hist_dev != nullptr, p->math_mode, p->slab32, nullptr, 0, s, &blocks);
@@ -490,6 +491,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
     if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs width %% 128 == 0 (got %u)", w);
     const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
     if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
     int n_cu = 0;
@@ -568,6 +570,140 @@ extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
     hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(256), 0, (hipStream_t)stream, b->slab64, b->blocks,
                        (unsigned long long *)hist_dev);
     RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_exporter: develop -> HBM slot -> pinned host slot, copy stream overlapping the compute stream
+// ------------------------------------------------------------------------------------------------
+struct rd_export_slot {
+    void *dev = nullptr;
+    void *host = nullptr;
+    hipEvent_t kernel_done = nullptr, copy_done = nullptr;
+    bool busy = false, used = false;
+};
+
+struct rd_exporter {
+    int device = 0;
+    uint32_t w = 0, h = 0, fmt = 0, math_mode = RD_MATH_STRICT, n_slots = 0, next = 0;
+    size_t bytes = 0;
+    rd_launch_cfg cfg;
+    hipStream_t compute = nullptr, copy = nullptr;
+    rd_export_slot *slots = nullptr;
+    std::mutex mu;
+};
+
+extern "C" void rd_exporter_destroy(rd_exporter *e)
+{
+    if (!e) return;
+    {
+        rd_devguard g(e->device);
+        if (e->compute) (void)hipStreamSynchronize(e->compute);
+        if (e->copy) (void)hipStreamSynchronize(e->copy);
+        for (uint32_t i = 0; e->slots && i < e->n_slots; ++i) {
+            if (e->slots[i].dev) (void)hipFree(e->slots[i].dev);
+            if (e->slots[i].host) (void)hipHostFree(e->slots[i].host);
+            if (e->slots[i].kernel_done) (void)hipEventDestroy(e->slots[i].kernel_done);
+            if (e->slots[i].copy_done) (void)hipEventDestroy(e->slots[i].copy_done);
+        }
+        if (e->compute) (void)hipStreamDestroy(e->compute);
+        if (e->copy) (void)hipStreamDestroy(e->copy);
+    }
+    delete[] e->slots;
+    delete e;
+}
+
+extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t math_mode, uint32_t n_slots,
+                                  rd_exporter **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!w || !h || !n_slots || n_slots > 64) return rd_fail(RD_ERR_INVALID_ARG, "bad frame size or slot count");
+    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "export needs an even frame width (got %u)", w);
+    const size_t bpp = rd_format_bytes_per_pixel(fmt);
+    if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 export needs width %% 128 == 0 (got %u)", w);
+    if (math_mode != RD_MATH_STRICT && math_mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", math_mode);
+    if (!(rd_identity_map(w) && rd_identity_map(h))) return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h);
+    int n_cu = 0;
+    int rc = rd_check_device(device, &n_cu);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rd_exporter *e = new (std::nothrow) rd_exporter;
+    if (!e) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    e->device = device; e->w = w; e->h = h; e->fmt = fmt; e->math_mode = math_mode; e->n_slots = n_slots;
+    e->bytes = (size_t)w * h * bpp;
+    e->cfg.n_cu = n_cu;
+    e->slots = new (std::nothrow) rd_export_slot[n_slots];
+    hipError_t err = e->slots ? hipSuccess : hipErrorOutOfMemory;
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
+    for (uint32_t i = 0; err == hipSuccess && i < n_slots; ++i) {
+        err = hipMalloc(&e->slots[i].dev, e->bytes);
+        if (err == hipSuccess) err = hipHostMalloc(&e->slots[i].host, e->bytes, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].kernel_done, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].copy_done, hipEventDisableTiming);
+    }
+    if (err != hipSuccess) {
+        int code = rd_fail(err == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "exporter setup failed: %s", hipGetErrorString(err));
+        rd_exporter_destroy(e);
+        return code;
+    }
+    *out = e;
+    return RD_OK;
+}
+
+extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out)
+{
+    if (!e || !fr || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!fr->cfa_dev || ((uintptr_t)fr->cfa_dev % 4u)) return rd_fail(RD_ERR_INVALID_ARG, "cfa_dev NULL or not 4-byte aligned");
+    rd_devguard g(e->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const uint32_t si = e->next;
+    rd_export_slot &s = e->slots[si];
+    if (s.busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u has not been released (ring of %u full)", si, e->n_slots);
+    // the previous copy out of this HBM slot must have finished before the kernel overwrites it
+    if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
+    const rd_ku u = rd_make_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode);
+    int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
+                               e->math_mode, nullptr, nullptr, 0, e->compute, nullptr);
+    if (rc) return rc;
+    RD_HIP(hipEventRecord(s.kernel_done, e->compute));
+    RD_HIP(hipStreamWaitEvent(e->copy, s.kernel_done, 0));
+    RD_HIP(hipMemcpyAsync(s.host, s.dev, e->bytes, hipMemcpyDeviceToHost, e->copy));
+    RD_HIP(hipEventRecord(s.copy_done, e->copy));
+    s.busy = true; s.used = true;
+    e->next = (si + 1u) % e->n_slots;
+    *slot_out = si;
+    return RD_OK;
+}
+
+extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len)
+{
+    if (!e || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
+    rd_devguard g(e->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->slots[slot].busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u holds no frame", slot);
+        ev = e->slots[slot].copy_done;
+    }
+    RD_HIP(hipEventSynchronize(ev));
+    *data = e->slots[slot].host;
+    if (len) *len = e->bytes;
+    return RD_OK;
+}
+
+extern "C" int rd_exporter_release(rd_exporter *e, uint32_t slot)
+{
+    if (!e) return rd_fail(RD_ERR_INVALID_ARG, "NULL exporter");
+    if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->slots[slot].busy = false;
     return RD_OK;
 }
 

@@ -205,6 +205,9 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
         rd_h2 hi = { (_Float16)c.b, (_Float16)1.0f };
         rd_u2 v = { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
         __builtin_nontemporal_store(v, reinterpret_cast<rd_u2 *>(out) + px);
+    } else if (FMT == RD_FMT_RGB_U8) {
+        uint8_t *o = reinterpret_cast<uint8_t *>(out) + px * 3u;    // small targets only: three byte stores
+        o[0] = (uint8_t)qr; o[1] = (uint8_t)qg; o[2] = (uint8_t)qb;
     } else {
         uint32_t v = qr | (qg << 8) | (qb << 16) | 0xff000000u;
         __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(out) + px);
@@ -257,6 +260,7 @@ template <int FMT> struct rd_tile_out;
 template <> struct rd_tile_out<RD_FMT_RGBA_F32> { rd_rgb c1, c2, c3; };
 template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
 template <> struct rd_tile_out<RD_FMT_RGBA_U8> { uint32_t v1, v2, v3; };
+template <> struct rd_tile_out<RD_FMT_RGB_U8> { uint32_t v1, v2, v3; };                   // 0x00bbggrr
 
 template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
 __global__ void __launch_bounds__(RD_BLOCK)
@@ -267,6 +271,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
+    __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     if (HIST) rd_hist_zero(lh);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -302,7 +307,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
         const rd_rgb c2 = RD_COLOUR(u, C, D, A);
         const rd_rgb c3 = RD_COLOUR(u, C, D, B);
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
-        if (HIST || FMT == RD_FMT_RGBA_U8) {
+        if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
             q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
             q3r = rd_q8(c3.r); q3g = rd_q8(c3.g); q3b = rd_q8(c3.b);
@@ -321,6 +326,10 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             r.a0 = __builtin_bit_cast(uint32_t, a_rg); r.a1 = __builtin_bit_cast(uint32_t, a_b1);
             r.b0 = __builtin_bit_cast(uint32_t, b_rg); r.b1 = __builtin_bit_cast(uint32_t, b_b1);
             r.c0 = __builtin_bit_cast(uint32_t, c_rg); r.c1 = __builtin_bit_cast(uint32_t, c_b1);
+        } else if constexpr (FMT == RD_FMT_RGB_U8) {
+            r.v1 = q1r | (q1g << 8) | (q1b << 16);
+            r.v2 = q2r | (q2g << 8) | (q2b << 16);
+            r.v3 = q3r | (q3g << 8) | (q3b << 16);
         } else {
             r.v1 = q1r | (q1g << 8) | (q1b << 16) | 0xff000000u;
             r.v2 = q2r | (q2g << 8) | (q2b << 16) | 0xff000000u;
@@ -367,6 +376,35 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
                 __builtin_nontemporal_store(va, o + (row_a_px >> 1) + q);
                 __builtin_nontemporal_store(vb, o + (row_b_px >> 1) + q);
             }
+        } else if constexpr (FMT == RD_FMT_RGB_U8) {
+            // 2 px = 6 B per lane per row: repack the wave's 384-B rows through LDS (three 16-bit writes per
+            // lane and row) and store whole dwords: lane l stores dword l, lanes 0..31 also dword 64+l.
+            // Full tiles only (the host routes other widths to rd_develop_map): W % 128 == 0 makes every
+            // row start and tile start a multiple of 4 bytes.
+            uint16_t *s16 = rgb16 + (size_t)wave * 384u;
+            uint32_t pa = r.v1, pb = r.v1, pc = r.v2, pd = r.v3;       // row a: (c1,c1)  row b: (c2,c3)
+            if (!has_a) { pa = pc; pb = pd; }
+            if (!has_b) { pc = pa; pd = pb; }
+            s16[lane * 3u + 0u] = (uint16_t)(pa & 0xffffu);                            // r0 g0
+            s16[lane * 3u + 1u] = (uint16_t)((pa >> 16) | ((pb & 0xffu) << 8));        // b0 r1
+            s16[lane * 3u + 2u] = (uint16_t)(pb >> 8);                                 // g1 b1
+            s16[192u + lane * 3u + 0u] = (uint16_t)(pc & 0xffffu);
+            s16[192u + lane * 3u + 1u] = (uint16_t)((pc >> 16) | ((pd & 0xffu) << 8));
+            s16[192u + lane * 3u + 2u] = (uint16_t)(pd >> 8);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s16);
+            uint32_t *oa = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + (row_a_px + (size_t)tq * 128u) * 3u);
+            uint32_t *ob = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + (row_b_px + (size_t)tq * 128u) * 3u);
+            const uint32_t a0 = s32[lane], b0 = s32[96u + lane];
+            const uint32_t l2 = lane & 31u;
+            const uint32_t a1 = s32[64u + l2], b1 = s32[160u + l2];
+            __builtin_nontemporal_store(a0, oa + lane);
+            __builtin_nontemporal_store(b0, ob + lane);
+            if (lane < 32u) {
+                __builtin_nontemporal_store(a1, oa + 64u + lane);
+                __builtin_nontemporal_store(b1, ob + 64u + lane);
+            }
+            __builtin_amdgcn_wave_barrier();
         } else {
             rd_u2 *o = reinterpret_cast<rd_u2 *>(out);                 // 2 px = 8 B per lane per row
             rd_u2 va = { r.v1, r.v1 }, vb = { r.v2, r.v3 };
@@ -494,7 +532,7 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
             c = rd_colour_m<MATH>(u, r, g, b);
         }
         uint32_t qr = 0, qg = 0, qb = 0;
-        if (HIST || FMT == RD_FMT_RGBA_U8) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }
+        if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }
         rd_store_px<FMT>(out, idx, c, qr, qg, qb);
         if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 1u);
     }

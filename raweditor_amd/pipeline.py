@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import FMT_RGBA_F16, FMT_RGBA_F32, FMT_RGBA_U8, BYTES_PER_PIXEL, RawdevError, check
+from ._lib import FMT_RGBA_F16, FMT_RGBA_F32, FMT_RGBA_U8, FMT_RGB_U8, BYTES_PER_PIXEL, RawdevError, check
 from .edit import EditParams
 
 IDENTITY_MATRIX = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
@@ -116,10 +116,10 @@ class RenderPipeline:
         (h, w, 4) array (float32 / float16 / uint8) and, if requested, the fused (3,256) histogram."""
         w = self.width if out_w is None else int(out_w)
         h = self.height if out_h is None else int(out_h)
-        dt = {FMT_RGBA_F32: np.float32, FMT_RGBA_F16: np.float16, FMT_RGBA_U8: np.uint8}.get(fmt)
+        dt = {FMT_RGBA_F32: np.float32, FMT_RGBA_F16: np.float16, FMT_RGBA_U8: np.uint8, FMT_RGB_U8: np.uint8}.get(fmt)
         if dt is None:
             raise RawdevError(-1, f"unknown format {fmt}")
-        out = np.empty((h, w, 4), dt)
+        out = np.empty((h, w, 3 if fmt == FMT_RGB_U8 else 4), dt)
         hist = np.zeros(768, np.uint32) if with_histogram else None
         check(_lib.lib().rd_render(self._h, w, h, fmt, out.ctypes.data_as(C.c_void_p), out.nbytes,
                                    hist.ctypes.data_as(C.c_void_p) if with_histogram else None))

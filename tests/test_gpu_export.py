@@ -1,0 +1,85 @@
+"""-m gpu: the export feed (rd_exporter_*, RD_FMT_RGB_U8) -- SURVEY.md section 8f rank 1.  Bytes must equal the
+oracle's RGBA8 pack (pipeline.rs:322), with alpha dropped for RGB8 exactly like main.rs:1777-1786."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import DevBuf
+from tests.helpers import CM_IDENTITY, CM_TEST, WB_DAYLIGHT, random_cfa, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(refc, cfa, p, rgb):
+    u = refc.make_uniforms(p, WB_DAYLIGHT, CM_TEST)
+    u8 = refc.pack_u8(refc.render_f32(cfa, u))
+    return u8[..., :3] if rgb else u8
+
+
+@pytest.mark.parametrize("fmt_name", ["RGBA8", "RGB8"])
+def test_exporter_ring(gpu_lib, refc, fmt_name):
+    ra = gpu_lib
+    fmt = ra.FMT_RGB_U8 if fmt_name == "RGB8" else ra.FMT_RGBA_U8
+    h, w, n = 70, 256, 7
+    rng = np.random.default_rng([5, fmt])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    ps = [random_params(rng) for _ in range(n)]
+    dev = [DevBuf.from_array(c) for c in cfas]
+    ex = ra.Exporter(0, w, h, fmt, n_slots=3)
+    frames = [ex.frame(d.ptr, ra.EditParams(**p), WB_DAYLIGHT, CM_TEST) for d, p in zip(dev, ps)]
+    seen = []
+    for i, surf in ex.export(frames):
+        assert surf.shape == (h, w, 3 if fmt_name == "RGB8" else 4)
+        assert np.array_equal(surf, _expected(refc, cfas[i], ps[i], fmt_name == "RGB8")), i
+        seen.append(i)
+    assert seen == list(range(n))
+    # ring discipline: a slot must be released before it is reused
+    slots = [ex.submit(frames[k]) for k in range(3)]
+    with pytest.raises(ra.RawdevError):
+        ex.submit(frames[3])
+    ex.wait(slots[0])
+    ex.release(slots[0])
+    s = ex.submit(frames[3])
+    assert s == slots[0]
+    assert np.array_equal(ex.wait(s), _expected(refc, cfas[3], ps[3], fmt_name == "RGB8"))
+    ex.close()
+
+
+def test_rgb8_surface_through_the_pipeline(gpu_lib, refc):
+    """RD_FMT_RGB_U8 via rd_render: export kernel (W % 128 == 0), map kernel (other widths, preview), edges."""
+    ra = gpu_lib
+    rng = np.random.default_rng(8)
+    for h, w in ((2, 128), (3, 128), (66, 384), (9, 13), (16, 24), (64, 130)):
+        cfa = random_cfa(rng, h, w)
+        p = random_params(rng)
+        pipe = ra.RenderPipeline.new(1, cfa.reshape(-1), w, h, ra.EditParams(**p), WB_DAYLIGHT, CM_TEST)
+        got, hist = pipe.render(fmt=ra.FMT_RGB_U8, with_histogram=True)
+        exp = _expected(refc, cfa, p, True)
+        assert got.shape == (h, w, 3) and np.array_equal(got, exp), (h, w)
+        assert np.array_equal(hist, refc.histogram(_expected(refc, cfa, p, False)))
+        small = pipe.render(11, 5, ra.FMT_RGB_U8)
+        u = refc.make_uniforms(p, WB_DAYLIGHT, CM_TEST)
+        assert np.array_equal(small, refc.pack_u8(refc.render_f32(cfa, u, 11, 5))[..., :3])
+    with pytest.raises(ra.RawdevError):
+        ra.Exporter(0, 130, 64, ra.FMT_RGB_U8)          # RGB8 export needs W % 128 == 0
+    with pytest.raises(ra.RawdevError):
+        ra.Exporter(0, 128, 64, ra.FMT_RGBA_U8, n_slots=0)
+
+
+def test_exporter_full_size_rgb8(gpu_lib, refc):
+    """6016 x 4016 through the ring; sampled bands against the oracle + alpha-strip consistency with RGBA8."""
+    ra = gpu_lib
+    h, w = 4016, 6016
+    rng = np.random.default_rng(24)
+    cfa = random_cfa(rng, h, w)
+    p = random_params(rng)
+    d = DevBuf.from_array(cfa)
+    u = refc.make_uniforms(p, WB_DAYLIGHT, CM_TEST)
+    ex3 = ra.Exporter(0, w, h, ra.FMT_RGB_U8, n_slots=2)
+    ex4 = ra.Exporter(0, w, h, ra.FMT_RGBA_U8, n_slots=2)
+    f3 = ex3.frame(d.ptr, ra.EditParams(**p), WB_DAYLIGHT, CM_TEST)
+    s3, s4 = ex3.submit(f3), ex4.submit(f3)
+    rgb, rgba = ex3.wait(s3), ex4.wait(s4)
+    assert np.array_equal(rgb, rgba[..., :3]) and np.all(rgba[..., 3] == 255)
+    for r0, r1 in ((0, 4), (2007, 2011), (h - 4, h)):
+        assert np.array_equal(rgb[r0:r1], refc.pack_u8(refc.render_band(cfa, u, r0, r1))[..., :3])
+    ex3.close(); ex4.close()
