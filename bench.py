@@ -109,10 +109,17 @@ def main():
     import torch.distributed as dist
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RAWDEV_DIST_BACKEND=gloo is a rehearsal mode for a 1-GPU box: several ranks share device 0 and the
+    # histogram all-reduce goes over gloo (RCCL refuses two ranks on one device).  The driver's runs use nccl.
+    backend = os.environ.get("RAWDEV_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import raweditor_amd as ra
     from raweditor_amd.batch import allreduce_histogram
@@ -135,7 +142,7 @@ def main():
     torch.cuda.synchronize()
 
     math_mode = ra.MATH_CONTRACTED if args.math == "contracted" else ra.MATH_STRICT
-    be = ra.BatchExporter(local_rank, W, H, fmt, with_hist, math_mode=math_mode)
+    be = ra.BatchExporter(dev_index, W, H, fmt, with_hist, math_mode=math_mode)
     frames = be.make_frames([c.data_ptr() for c in cfas], [ring[i % len(ring)].data_ptr() for i in range(F)],
                             params, WB, CM)
     stream = torch.cuda.Stream(device=dev)
@@ -219,7 +226,7 @@ def main():
     if world == 1 and not args.no_alt_math:
         # Reported-only: the same workload in the other arithmetic, 5 steps.
         other = "contracted" if args.math == "strict" else "strict"
-        be2 = ra.BatchExporter(local_rank, W, H, fmt, with_hist,
+        be2 = ra.BatchExporter(dev_index, W, H, fmt, with_hist,
                                math_mode=ra.MATH_CONTRACTED if other == "contracted" else ra.MATH_STRICT)
         with torch.cuda.stream(stream):
             be2.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
