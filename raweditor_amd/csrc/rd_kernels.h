@@ -270,7 +270,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
 {
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
-    __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
+    __shared__ rd_f4 stage[(FMT == RD_FMT_RGBA_F32 || BURST) ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     if (HIST) rd_hist_zero(lh);
 
@@ -418,37 +418,81 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
     };
 
     if (tile < ntiles) {
+        uint32_t top, bot;
         if (BURST) {
-            // ---- phase 0 (f32 surface only: the other surfaces are VALU-bound and gain nothing): read-only burst.  HBM3E serves this kernel's 1:8 read:write mix badly when
-            // 256-B reads are sprinkled between the write streams: every isolated read costs the DRAM
-            // channel a write->read->write turnaround (measured: the same bytes take 85-88 us mixed but
-            // 65 us when the CFA plane is already in the Infinity Cache).  So every wave first touches
-            // ALL the CFA lines it is going to need, eight loads in flight at a time; the whole chip is
-            // in this phase together (persistent grid, nothing stored yet), the 48 MB land in the 256 MiB
-            // Infinity Cache in one pure-read burst, and the main loop's loads are served on-die.
-            // nt stores do not displace them (measured).
-            // The sweep need not follow the tile ownership: any wave may pull any line into the (shared)
-            // Infinity Cache, so it is a plain coalesced pass over this launch's rows, 16 B per lane.
+            // ---- read-only burst (f32 surface only: the other surfaces are VALU-bound and gain nothing).
+            // HBM3E serves this kernel's 1:8 read:write mix badly when 256-B reads are sprinkled between the
+            // write streams: every isolated read costs the DRAM channel a write->read->write turnaround
+            // (measured: the same bytes take 85-88 us mixed but 65 us when the CFA plane is already in the
+            // Infinity Cache).  So before anything is stored the grid sweeps this launch's CFA rows once,
+            // 16 B per lane, fire-and-forget: LDS-DMA loads (global_load_lds_dwordx4) into this wave's
+            // not-yet-used store stage, so no VGPR is tied up and nothing waits for the data.  The whole
+            // chip is in this phase together (persistent grid, nothing stored yet); the 48 MB land in the
+            // 256 MiB Infinity Cache in one pure-read burst while every wave computes its first tile, and
+            // the main loop's loads are served on-die.  nt stores do not displace the lines (measured).
+            // Any wave may pull any line (the cache is shared), so the sweep ignores tile ownership.  The
+            // count is static (8 x 1 KiB per wave covers 64 MB per launch) so the compiler can still count
+            // vmcnt for the tile-0 loads issued above; larger launches finish with a waited loop.
             typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
             const uint32_t row_lo = unit0 ? 2u * unit0 - 1u : 0u;
             const uint32_t row_hi = 2u * (unit1 - 1u) < H ? 2u * (unit1 - 1u) + 1u : H;       // exclusive
             const rd_u4 *src = reinterpret_cast<const rd_u4 *>(cfa + (size_t)row_lo * W);
             const size_t n16 = ((size_t)(row_hi - row_lo) * W * sizeof(uint16_t)) / 16u;       // whole 16-B chunks
-            const size_t gw = (size_t)(blockIdx.x * RD_WAVES + wave) * 64u + lane, gstride = (size_t)nwaves * 64u;
-            uint32_t sink = 0;
-            if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
-                for (size_t i0 = gw; i0 < n16; i0 += 4 * gstride) {
-                    rd_u4 v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { const size_t ii = i0 + k * gstride; v[k] = src[ii < n16 ? ii : gw]; }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sink ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+            const size_t g0 = (size_t)(blockIdx.x * RD_WAVES + wave) * 64u, gstride = (size_t)nwaves * 64u;
+            // (host guarantees for BURST launches: cfa 16-byte aligned, W % 128 == 0, at least 1 MB of CFA rows,
+            //  so src is aligned, n16 >= 64 and every instruction below is unconditional)
+            {                                                    // launches > 64 MB only: the part beyond 8 x 1 KiB per wave
+                uint32_t sink = 0;
+                for (size_t i0 = g0 + 8u * gstride; i0 + 64u <= n16; i0 += gstride) {
+                    const rd_u4 v = src[i0 + lane];
+                    sink ^= v.x ^ v.y ^ v.z ^ v.w;
                 }
+                asm volatile("" ::"v"(sink));
             }
-            asm volatile("" ::"v"(sink));
+            // Tile-0 loads + the eight LDS-DMA sweeps + "wait for the two loads only" as ONE asm statement:
+            // hipcc does not count LDS-DMA instructions in its vmcnt bookkeeping and would wait vmcnt(0) for
+            // the tile-0 data, i.e. for the whole burst.  Inside the statement the order is ours: the two
+            // loads are the oldest of ten outstanding operations, so vmcnt(8) is exactly "they have landed".
+            // Nothing else is in flight here (first memory instructions of the wave after the waited loop).
+            {
+                uint32_t q = qt * 64u + lane;
+                const uint32_t ra = unit ? 2u * unit - 1u : 0u;
+                const uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
+                const uint32_t *pt = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W) + q;
+                const uint32_t *pb = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W) + q;
+                const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(stage + (size_t)wave * 192u));
+                const rd_u4 *a[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    size_t i0 = g0 + (size_t)k * gstride;
+                    i0 = i0 + 64u <= n16 ? i0 : 0;               // wave-uniform clamp: re-touch the first chunk
+                    a[k] = src + i0 + lane;
+                }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("global_load_dword %0, %2, off\n\t"
+                             "global_load_dword %1, %3, off\n\t"
+                             "s_mov_b32 m0, %4\n\t"
+                             "s_nop 0\n\t"
+                             "global_load_lds_dwordx4 %5, off\n\t"
+                             "global_load_lds_dwordx4 %6, off\n\t"
+                             "global_load_lds_dwordx4 %7, off\n\t"
+                             "global_load_lds_dwordx4 %8, off\n\t"
+                             "global_load_lds_dwordx4 %9, off\n\t"
+                             "global_load_lds_dwordx4 %10, off\n\t"
+                             "global_load_lds_dwordx4 %11, off\n\t"
+                             "global_load_lds_dwordx4 %12, off\n\t"
+                             "s_waitcnt vmcnt(8)"
+                             : "=&v"(top), "=&v"(bot)
+                             : "v"(pt), "v"(pb), "s"(lds_base), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]),
+                               "v"(a[5]), "v"(a[6]), "v"(a[7])
+                             : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        } else {
+            load_tile(unit, qt, top, bot);
         }
-        uint32_t top, bot;
-        load_tile(unit, qt, top, bot);
         // Land the first tile's loads BEFORE the loop.  hipcc places one static s_waitcnt per use and
         // merges the loop-entry and back-edge states; with loads still pending at the loop header it
         // emits vmcnt(1)/vmcnt(2) there, which on the back edge means "drain the stores in flight".
