@@ -362,8 +362,13 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
                 if (!has_a) va = vb;
                 if (!has_b) vb = va;
                 if (FULL || px < W) {
+#ifdef RD_ST_PLAIN
+                    o[row_a_px + px] = va;
+                    o[row_b_px + px] = vb;
+#else
                     __builtin_nontemporal_store(va, o + row_a_px + px);
                     __builtin_nontemporal_store(vb, o + row_b_px + px);
+#endif
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,151 @@
+"""CFA ingest without rawloader -- the step BEFORE the path.
+
+The reference decodes RAW files with the third-party `rawloader` crate (src/raw/loader.rs:50-54); its
+source is not in the tree, so NEF decoding is out of scope and this module does NOT claim rawloader parity
+("parity unpinned": there is nothing of the reference's to check a decoder against).  What IS restated
+exactly is everything loader.rs does AFTER the decode (src/raw/loader.rs:57-152), which defines the
+`RawDataResult` the develop path is fed:
+
+  * integer samples are taken as they are; float samples become clamp(v*65535, 0, 65535) as u16 (:62-73);
+  * white balance: 4 coefficients, or 3 with G2 := G, or neutral; divided by max(G, 0.001); a non-finite
+    or non-positive G2 falls back to G (:78-110);
+  * colour matrix: the first 3 columns of the first 3 rows of xyz_to_cam if [0][0] or [1][1] is non-zero,
+    else identity (:115-134).
+
+Two containers are read: a headerless u16 plane (dimensions from the caller / the catalog row), and
+uncompressed 16-bit CFA DNG/TIFF (Compression = 1, one sample per pixel).  No pixel arithmetic happens
+here -- the samples go to HBM untouched.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import os
+import struct
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclasses.dataclass
+class RawDataResult:
+    """src/raw/loader.rs:11-19."""
+    data: np.ndarray                 # uint16, length width*height, row-major
+    width: int
+    height: int
+    wb_multipliers: List[float]      # [R/G, 1, B/G, G2/G]
+    color_matrix: List[float]        # xyz_to_cam 3x3 row-major (or identity)
+
+
+def normalise_wb(wb_coeffs: Sequence[float]) -> List[float]:
+    """loader.rs:78-110, f32 arithmetic."""
+    f = np.float32
+    c = [f(x) for x in wb_coeffs]
+    if len(c) >= 4:
+        wb = c[:4]
+    elif len(c) >= 3:
+        wb = [c[0], c[1], c[2], c[1]]
+    else:
+        wb = [f(1.0)] * 4
+    g = max(wb[1], f(0.001))
+    g2 = wb[3] / g if (math.isfinite(float(wb[3])) and wb[3] > 0) else wb[1] / g
+    return [float(wb[0] / g), float(wb[1] / g), float(wb[2] / g), float(g2)]
+
+
+def extract_matrix(xyz_to_cam: Optional[Sequence[Sequence[float]]]) -> List[float]:
+    """loader.rs:115-134: rows 0..2, columns 0..2 of the [3+][3 or 4] matrix, or identity."""
+    if xyz_to_cam is not None and (xyz_to_cam[0][0] != 0.0 or xyz_to_cam[1][1] != 0.0):
+        return [float(np.float32(xyz_to_cam[r][c])) for r in range(3) for c in range(3)]
+    return [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+
+
+def samples_to_u16(values: np.ndarray) -> np.ndarray:
+    """loader.rs:62-73."""
+    values = np.asarray(values)
+    if values.dtype.kind == "f":
+        v = values.astype(np.float32) * np.float32(65535.0)
+        return np.clip(v, np.float32(0.0), np.float32(65535.0)).astype(np.uint16)
+    return values.astype(np.uint16, copy=False)
+
+
+def load_raw_u16(path: str, width: int, height: int, wb_coeffs: Sequence[float] = (),
+                 xyz_to_cam: Optional[Sequence[Sequence[float]]] = None, memmap: bool = True) -> RawDataResult:
+    """Headerless little-endian u16 plane.  Errors mirror loader.rs:46-48 ("File not found: ...")."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"File not found: {path}")
+    n = int(width) * int(height)
+    if os.path.getsize(path) != 2 * n:
+        raise ValueError(f"{path}: {os.path.getsize(path)} bytes, expected {2 * n} for {width}x{height} u16")
+    data = np.memmap(path, dtype="<u2", mode="r", shape=(n,)) if memmap else np.fromfile(path, dtype="<u2")
+    return RawDataResult(data, int(width), int(height), normalise_wb(wb_coeffs), extract_matrix(xyz_to_cam))
+
+
+# ---- minimal TIFF / DNG ----------------------------------------------------------------------------------
+_TYPE_SIZE = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 7: 1, 8: 2, 9: 4, 10: 8, 11: 4, 12: 8}
+_TYPE_FMT = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 11: "f", 12: "d"}
+TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
+TAG_STRIP_OFFSETS, TAG_SPP, TAG_ROWS_PER_STRIP, TAG_STRIP_BYTES, TAG_SUBIFD = 273, 277, 278, 279, 330
+TAG_COLOR_MATRIX1, TAG_AS_SHOT_NEUTRAL = 50721, 50728
+PHOTOMETRIC_CFA = 32803
+
+
+def _read_ifd(buf: bytes, off: int, e: str):
+    (n,) = struct.unpack_from(e + "H", buf, off)
+    tags = {}
+    for i in range(n):
+        tag, typ, cnt, val = struct.unpack_from(e + "HHI4s", buf, off + 2 + 12 * i)
+        size = _TYPE_SIZE.get(typ, 1) * cnt
+        raw = val[:size] if size <= 4 else buf[struct.unpack(e + "I", val)[0]:][:size]
+        if typ in (5, 10):                                  # (S)RATIONAL
+            ints = struct.unpack(e + ("I" if typ == 5 else "i") * (2 * cnt), raw)
+            vals = [ints[2 * k] / ints[2 * k + 1] if ints[2 * k + 1] else 0.0 for k in range(cnt)]
+        elif typ in _TYPE_FMT:
+            vals = list(struct.unpack(e + _TYPE_FMT[typ] * cnt, raw))
+        else:
+            vals = [raw]
+        tags[tag] = vals
+    (nxt,) = struct.unpack_from(e + "I", buf, off + 2 + 12 * n)
+    return tags, nxt
+
+
+def load_dng_uncompressed(path: str) -> RawDataResult:
+    """Uncompressed (Compression = 1) 16-bit single-sample CFA image from a DNG/TIFF; anything else is an error."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"File not found: {path}")
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if buf[:2] == b"II":
+        e = "<"
+    elif buf[:2] == b"MM":
+        e = ">"
+    else:
+        raise ValueError("Failed to decode RAW: not a TIFF container")
+    magic, off = struct.unpack_from(e + "HI", buf, 2)
+    if magic != 42:
+        raise ValueError("Failed to decode RAW: bad TIFF magic")
+    todo, ifds = [off], []
+    while todo:
+        o = todo.pop(0)
+        if not o or o >= len(buf):
+            continue
+        tags, nxt = _read_ifd(buf, o, e)
+        ifds.append(tags)
+        todo.extend(tags.get(TAG_SUBIFD, []))
+        todo.append(nxt)
+    raw = next((t for t in ifds if t.get(TAG_PHOTOMETRIC, [None])[0] == PHOTOMETRIC_CFA), None)
+    if raw is None:
+        raise ValueError("Failed to decode RAW: no CFA image in the file")
+    if raw.get(TAG_COMPRESSION, [1])[0] != 1 or raw.get(TAG_BITS, [0])[0] != 16 or raw.get(TAG_SPP, [1])[0] != 1:
+        raise ValueError("Failed to decode RAW: only uncompressed 16-bit single-sample CFA data is supported")
+    w, h = raw[TAG_WIDTH][0], raw[TAG_LENGTH][0]
+    parts = [np.frombuffer(buf, dtype=e + "u2", count=nbytes // 2, offset=o)
+             for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES])]
+    data = np.concatenate(parts).astype(np.uint16) if len(parts) > 1 else parts[0].astype(np.uint16)
+    if data.size != w * h:
+        raise ValueError(f"Failed to decode RAW: {data.size} samples for {w}x{h}")
+    meta = ifds[0]
+    neutral = meta.get(TAG_AS_SHOT_NEUTRAL) or raw.get(TAG_AS_SHOT_NEUTRAL)
+    wb = [1.0 / x if x else 0.0 for x in neutral[:3]] if neutral else []      # multipliers = 1 / neutral
+    cm = meta.get(TAG_COLOR_MATRIX1) or raw.get(TAG_COLOR_MATRIX1)
+    xyz_to_cam = [cm[0:3], cm[3:6], cm[6:9]] if cm and len(cm) >= 9 else None
+    return RawDataResult(data, int(w), int(h), normalise_wb(wb), extract_matrix(xyz_to_cam))

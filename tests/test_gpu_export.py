@@ -83,3 +83,49 @@ def test_exporter_full_size_rgb8(gpu_lib, refc):
     for r0, r1 in ((0, 4), (2007, 2011), (h - 4, h)):
         assert np.array_equal(rgb[r0:r1], refc.pack_u8(refc.render_band(cfa, u, r0, r1))[..., :3])
     ex3.close(); ex4.close()
+
+
+def test_catalog_to_export_end_to_end(gpu_lib, refc, tmp_path):
+    """The caller's flow (main.rs:973-1006 then :1744-1799) with this build's pieces on both sides of the path:
+    DNG / u16 ingest -> RawDataResult -> identity matrix stub -> edits from the app's SQLite table -> export ring."""
+    import sqlite3
+    from raweditor_amd import catalog, ingest
+    from tests.test_ingest_catalog_cpu import _write_dng
+    ra = gpu_lib
+    rng = np.random.default_rng(31)
+    h, w = 40, 128
+    conn = sqlite3.connect(tmp_path / "library.db")
+    catalog.init_schema(conn)
+    cfas, stacks = [], []
+    for k in range(4):
+        cfa = random_cfa(rng, h, w)
+        cfas.append(cfa)
+        if k % 2:
+            path = tmp_path / f"f{k}.dng"
+            _write_dng(path, cfa, "<", strips=2)
+        else:
+            path = tmp_path / f"f{k}.u16"
+            cfa.astype("<u2").tofile(path)
+        conn.execute("INSERT INTO images (path, filename, width, height, imported_at) VALUES (?,?,?,?,0)",
+                     (str(path), path.name, w, h))
+        if k != 3:                                         # image 4 has no edits -> default stack
+            p = ra.EditParams(**random_params(rng))
+            catalog.save_edit_params(conn, k + 1, p)
+            stacks.append(p)
+        else:
+            stacks.append(ra.EditParams())
+    conn.commit()
+    ex = ra.Exporter(0, w, h, ra.FMT_RGB_U8, n_slots=2)
+    keep, frames, wbs = [], [], []
+    for e in catalog.export_manifest(conn):
+        raw = (ingest.load_dng_uncompressed(e.path) if e.path.endswith(".dng")
+               else ingest.load_raw_u16(e.path, e.width, e.height, wb_coeffs=[2.0, 1.0, 1.5]))
+        cm = ra.calculate_cam_to_srgb_matrix(raw.color_matrix)          # identity, like the reference
+        d = DevBuf.from_array(np.asarray(raw.data))
+        keep.append(d)
+        wbs.append(raw.wb_multipliers)
+        frames.append(ex.frame(d.ptr, e.params, raw.wb_multipliers, cm))
+    for i, surf in ex.export(frames):
+        u = refc.make_uniforms({f: getattr(stacks[i], f) for f in ra.FIELDS}, wbs[i], CM_IDENTITY)
+        assert np.array_equal(surf, refc.pack_u8(refc.render_f32(cfas[i], u))[..., :3]), i
+    ex.close()
