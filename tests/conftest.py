@@ -13,6 +13,13 @@ SEED = 0x52415745  # "RAWE" 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout has no librawdev.so (built artefacts are git-ignored): build it once (hipcc cross-compiles
+    # gfx950 without a GPU, ~10 s).  If that is impossible the tests that need the library fail loudly.
+    try:
+        from raweditor_amd.build import build_library
+        build_library()
+    except Exception as e:  # noqa: BLE001
+        print(f"[conftest] could not build librawdev.so: {e}", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")
