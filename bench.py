@@ -80,6 +80,12 @@ def cpu_baseline(width, height, budget_s):
         if el >= budget_s or frames >= 16:
             break
     mp = frames * width * height / 1e6
+    # one-thread figure on a 256-row band of the same frame
+    band_h = min(256, height)
+    t1 = time.perf_counter()
+    L.ref_render_f32_mt(cfa.ctypes.data_as(C.POINTER(C.c_uint16)), width, band_h, C.byref(u), width, band_h, 0,
+                        out.ctypes.data_as(C.POINTER(C.c_float)), 1)
+    one_thread = width * band_h / 1e6 / (time.perf_counter() - t1)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -90,6 +96,7 @@ def cpu_baseline(width, height, budget_s):
     except OSError:
         pass
     return {"value": round(mp / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+            "one_thread_MPps": round(one_thread, 2),
             "sample": f"{frames} x {width}x{height} frame(s), randomised stack, f32 surface, "
                       f"{el:.1f} s on {cores} threads ({model})"}
 

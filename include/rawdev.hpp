@@ -91,6 +91,20 @@ struct EditParams : rd_edit_params {
     }
 };
 
+// color::calculate_cam_to_srgb_matrix (reference src/color.rs:35-47): the reference returns the identity for ANY
+// input (the real maths is commented out); color::is_identity_matrix (:172-178): |m - I| < 0.001 element-wise.
+inline std::array<float, 9> calculate_cam_to_srgb_matrix(const std::array<float, 9> & /*xyz_to_cam*/)
+{
+    return { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };
+}
+inline bool is_identity_matrix(const std::array<float, 9> &m)
+{
+    const float id[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };
+    for (int i = 0; i < 9; ++i)
+        if (!(std::fabs(m[i] - id[i]) < 0.001f)) return false;
+    return true;
+}
+
 using Histogram = std::array<std::array<uint32_t, 256>, 3>;
 
 // gpu::RenderPipeline.  Move-only owner of an rd_pipeline; share it across threads by reference or

@@ -26,6 +26,13 @@ def calculate_cam_to_srgb_matrix(xyz_to_cam: Sequence[float]) -> Tuple[float, ..
     return IDENTITY_MATRIX
 
 
+def is_identity_matrix(matrix: Sequence[float]) -> bool:
+    """color::is_identity_matrix (reference src/color.rs:172-178): every element within 0.001 of the identity."""
+    if len(matrix) != 9:
+        raise ValueError("matrix must have 9 elements")
+    return all(abs(float(np.float32(m)) - float(np.float32(i))) < 0.001 for m, i in zip(matrix, IDENTITY_MATRIX))
+
+
 def derived_dims(width: int, height: int) -> Tuple[int, int, int, int]:
     """(preview_w, preview_h, hist_w, hist_h) with pipeline.rs:125-133's truncating f32 arithmetic."""
     v = [C.c_uint32() for _ in range(4)]

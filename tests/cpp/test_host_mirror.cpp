@@ -43,6 +43,18 @@ static void test_reset()                          // edit.rs:152-163
     EXPECT(p.is_unedited());
 }
 
+static void test_color_stub()                     // color.rs:184-206
+{
+    EXPECT(rawdev::is_identity_matrix({ 1, 0, 0, 0, 1, 0, 0, 0, 1 }));
+    EXPECT(rawdev::is_identity_matrix({ 1.0005f, 0, 0, 0, 0.9995f, 0, 0, 0, 1 }));
+    EXPECT(!rawdev::is_identity_matrix({ 1.002f, 0, 0, 0, 1, 0, 0, 0, 1 }));
+    const auto m = rawdev::calculate_cam_to_srgb_matrix({ 0.8f, 0.1f, 0.1f, 0.2f, 0.7f, 0.1f, 0.0f, 0.3f, 0.9f });
+    EXPECT(rawdev::is_identity_matrix(m));          // the reference's stub returns identity unconditionally
+    bool any = false;
+    for (float v : m) any = any || v != 0.0f;
+    EXPECT(any);                                    // test_cam_to_srgb_calculation: "has a non-zero element"
+}
+
 static void test_errors_without_compute()
 {
     bool threw = false;
@@ -121,6 +133,7 @@ int main(int argc, char **argv)
     test_serialization();
     test_reset();
     test_errors_without_compute();
+    test_color_stub();
     if (gpu) {
         test_pipeline_gpu();
     } else {

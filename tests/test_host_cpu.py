@@ -64,6 +64,10 @@ def test_cam_to_srgb_is_identity_stub():
     # color.rs:35-47 returns identity for any input; color.rs:193-206 checks a non-zero element
     m = ra.calculate_cam_to_srgb_matrix([0.8, 0.1, 0.1, 0.2, 0.7, 0.1, 0.0, 0.3, 0.9])
     assert m == ra.IDENTITY_MATRIX
+    # color.rs:184-191 test_identity_matrix_detection
+    assert ra.is_identity_matrix([1, 0, 0, 0, 1, 0, 0, 0, 1])
+    assert ra.is_identity_matrix([1.0005, 0, 0, 0, 0.9995, 0, 0, 0, 1])
+    assert not ra.is_identity_matrix([1.002, 0, 0, 0, 1, 0, 0, 0, 1])
 
 
 # ---- the C ABI ------------------------------------------------------------------------------------------
