@@ -227,6 +227,39 @@ __global__ void __launch_bounds__(1024) mb_mix_deep(const uint32_t *__restrict__
     }
 }
 
+// write-pattern probe: a wave-tile = ROWS rows x RUN_KB KiB contiguous per row (no loads); block-major or
+// block-cyclic wave->tile order; ORDER 0 = all of row a then row b, ORDER 1 = 2-KiB pieces interleaved (a0 b0 a1 b1).
+template <int ROWS, int RUN_KB, bool CYCLIC, int ORDER = 0>
+__global__ void __launch_bounds__(1024) mb_wpat(float *__restrict__ out, uint32_t W, uint32_t H)
+{
+    const uint32_t lane = threadIdx.x & 63u, w_in_b = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * 16u;
+    const uint32_t wave = CYCLIC ? w_in_b * gridDim.x + blockIdx.x : blockIdx.x * 16u + w_in_b;
+    const uint32_t px_per_tile = RUN_KB * 64u;                    // 16 B per px
+    const uint32_t tpr = W / px_per_tile;
+    const uint32_t ntiles = (H / ROWS) * tpr;
+    rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
+    const rd_f4 val = { 0.25f, 0.5f, 0.75f, 1.0f };
+    for (uint32_t t = wave; t < ntiles; t += nwaves) {
+        const uint32_t rp = t / tpr, c0 = (t % tpr) * px_per_tile;
+        if (ORDER == 0) {
+#pragma unroll
+            for (uint32_t r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (uint32_t k = 0; k < RUN_KB; ++k)
+                    __builtin_nontemporal_store(val, o + (size_t)(rp * ROWS + r) * W + c0 + k * 64u + lane);
+        } else {
+#pragma unroll
+            for (uint32_t p = 0; p < RUN_KB / 2; ++p)
+#pragma unroll
+                for (uint32_t r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (uint32_t k = 0; k < 2; ++k)
+                        __builtin_nontemporal_store(val, o + (size_t)(rp * ROWS + r) * W + c0 + (p * 2 + k) * 64u + lane);
+        }
+    }
+}
+
 typedef float rd_f2 __attribute__((ext_vector_type(2)));
 // ---- VALU calibration: ITER x 16 independent ops per lane -----------------------------------------
 template <int KIND>
@@ -366,6 +399,16 @@ int main(int argc, char **argv)
     MIXC("mix 1:8 SAME input load16B x512", 16, true, 512);
     MIXC("mix 1:8 SAME input load4B x512", 4, true, 512);
     MIXC("mix 1:8 SAME input load16B x2048", 16, true, 2048);
+#define WPAT(NAME, ROWS, RUN, CYC, ORD, BLOCKS) vs.push_back({ NAME, [&](int k) { hipLaunchKernelGGL((mb_wpat<ROWS, RUN, CYC, ORD>), dim3(BLOCKS), dim3(1024), 0, s, dout[k % NOUT], W, H); }, {} })
+    WPAT("wpat 2rows x 2KB blockmajor x512", 2, 2, false, 0, 512);
+    WPAT("wpat 2rows x 2KB cyclic x512", 2, 2, true, 0, 512);
+    WPAT("wpat 2rows x 2KB cyclic x256", 2, 2, true, 0, 256);
+    WPAT("wpat 2rows x 4KB blockmajor x512", 2, 4, false, 0, 512);
+    WPAT("wpat 2rows x 4KB cyclic x512", 2, 4, true, 0, 512);
+    WPAT("wpat 2rows x 4KB cyclic a0b0a1b1 x512", 2, 4, true, 1, 512);
+    WPAT("wpat 2rows x 16KB cyclic x512", 2, 16, true, 0, 512);
+    WPAT("wpat 1row x 4KB blockmajor x512", 1, 4, false, 0, 512);
+    WPAT("wpat 1row x 1KB blockmajor x512", 1, 1, false, 0, 512);
     vs.push_back({ "fill contiguous nt", [&](int k) { hipLaunchKernelGGL(mb_fill, dim3(2048), dim3(1024), 0, s, dout[k % NOUT], out_bytes / 16, 1); }, {} });
     vs.push_back({ "fill contiguous plain", [&](int k) { hipLaunchKernelGGL(mb_fill, dim3(2048), dim3(1024), 0, s, dout[k % NOUT], out_bytes / 16, 0); }, {} });
 
