@@ -137,3 +137,20 @@ def test_shard_frames():
     assert allf == list(range(2048)) and all(len(ra.shard_frames(2048, r, 8)) == 256 for r in range(8))
     with pytest.raises(ValueError):
         ra.shard_frames(4, 4, 4)
+
+
+def test_product_never_reaches_into_the_oracle():
+    """oracle/ is test infrastructure: nothing under raweditor_amd/ or include/ may include, import or load it."""
+    bad = []
+    pats = [re.compile(p) for p in (r'#\s*include\s*[<"][^>"]*(oracle|develop_ref)', r'^\s*(from|import)\s+oracle\b',
+                                    r'libdevelop_ref', r'CDLL\([^)]*oracle')]
+    for base in ("raweditor_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                for line in text.splitlines():
+                    if any(p.search(line) for p in pats):
+                        bad.append((f, line.strip()))
+    assert not bad, bad
