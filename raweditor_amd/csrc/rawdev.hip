@@ -152,11 +152,15 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;   // A/B override: 0 / 1
     // read burst (rd_kernels.h): f32 surface by default; needs 16-byte aligned CFA rows and a launch worth it
     const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
-    const bool burst = burst_ok && (burst_env < 0 ? (FMT == RD_FMT_RGBA_F32) : burst_env != 0);
-    if (W % 128u == 0 && burst)
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                           unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
-    else if (W % 128u == 0)
+    const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && (burst_env < 0 || burst_env != 0);
+    if constexpr (FMT == RD_FMT_RGBA_F32) {     // the burst variant exists for the f32 surface only
+        if (W % 128u == 0 && burst) {
+            hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
+                               unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+            return;
+        }
+    }
+    if (W % 128u == 0)
         hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
                            unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
     else
