@@ -339,7 +339,17 @@ def test_full_size_24mp(gpu_lib, refc):
     assert np.array_equal(got8, refc.pack_u8(got))            # u8 surface == pack of the f32 surface
     assert np.array_equal(pipe.calculate_histogram(got8), hist)
     del got8, flat8
-    # (3) the export kernel and the general map kernel agree on every pixel of the full frame
+    # (3) linearity: doubling wb, or doubling every CFA sample, is bit-identical to one more stop of exposure
+    cfa_half = (cfa >> 1).astype(np.uint16)
+    p0 = dict(params, exposure=float(F(min(params["exposure"], 3.0))))
+    p1 = dict(p0, exposure=float(F(p0["exposure"] + 1.0)))
+    ref_lin = make_pipe(ra, cfa_half, p1, WB_DAYLIGHT, CM_TEST).render()
+    assert np.array_equal(make_pipe(ra, cfa_half, p0, tuple(2 * x for x in WB_DAYLIGHT), CM_TEST).render().view(np.uint32),
+                          ref_lin.view(np.uint32))
+    assert np.array_equal(make_pipe(ra, (cfa_half * 2).astype(np.uint16), p0, WB_DAYLIGHT, CM_TEST).render().view(np.uint32),
+                          ref_lin.view(np.uint32))
+    del ref_lin
+    # (4) the export kernel and the general map kernel agree on every pixel of the full frame
     with force_map():
         got_map = pipe.render(fmt=ra.FMT_RGBA_F32)
     assert np.array_equal(got_map.view(np.uint32), got.view(np.uint32))

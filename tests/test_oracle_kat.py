@@ -224,3 +224,19 @@ def test_contracted_default_stack_is_still_the_identity_chain(refc):
     cfa = np.full((4, 4), 2048, np.uint16)
     a = refc.render_f32(cfa, refc.make_uniforms(None, math_mode=refc.MATH_CONTRACTED))
     assert np.all(refc.pack_u8(a)[..., :3] == 186)
+
+
+# ---- size-independent properties of the path (used again at 24 MP on the GPU) -------------------------------
+def test_power_of_two_scaling_properties(refc, rng):
+    """Everything before the tone steps is linear and a factor 2 is exact in binary floating point, so
+    doubling the white balance, or doubling every CFA sample, is bit-identical to one more stop of exposure
+    (shaders.rs:195-218).  Holds for any slider stack, matrix and size."""
+    cfa = random_cfa(rng, 12, 16, 2048)                  # < 2048 so 2*cfa stays in u16 and below 4096
+    for _ in range(4):
+        p = random_params(rng)
+        p["exposure"] = float(F(rng.uniform(-4, 3)))
+        base = dict(p, exposure=float(F(p["exposure"] + 1.0)))
+        a = c_render(refc, cfa, base, WB_DAYLIGHT, CM_TEST)
+        b = c_render(refc, cfa, p, tuple(2 * x for x in WB_DAYLIGHT), CM_TEST)
+        c = c_render(refc, (cfa * 2).astype(np.uint16), p, WB_DAYLIGHT, CM_TEST)
+        assert ulp_diff(a, b) == 0 and ulp_diff(a, c) == 0
