@@ -140,7 +140,8 @@ int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format, v
               size_t dst_len, uint32_t hist[768]);
 /* Device-resident variant: `dst_dev` (and nullable `hist_dev`, 768 x u32) are device pointers on
  * the pipeline's device; work is enqueued on `stream` (a hipStream_t, NULL = default stream) and
- * NOT synchronised. */
+ * NOT synchronised.  The fused histogram uses scratch owned by the pipeline: renders WITH a histogram on one
+ * pipeline must be enqueued on one stream at a time (renders without one may overlap freely). */
 int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format,
                      void *dst_dev, uint32_t *hist_dev, void *stream);
 
@@ -155,7 +156,8 @@ typedef struct rd_frame {
     uint32_t black_level;
 } rd_frame;
 
-/* A batch context owns the per-stream histogram slabs for frames of one size/format on one device. */
+/* A batch context owns the histogram slab for frames of one size/format on one device.  Use one context per
+ * stream and per thread (the accumulator is private to the context; calls on one context are not re-entrant). */
 int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format,
                     uint32_t with_histogram, rd_batch **out);
 void rd_batch_destroy(rd_batch *b);
