@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 
@@ -142,13 +143,46 @@ struct rd_launch_cfg {
     uint32_t wg_per_cu_plain = 2;    // 2 x 1024 threads = the CU's 32 waves
 };
 
+// Ticket counters of the export kernel (rd_kernels.h, "Scheduling"): up to RD_MAX_BLOCKS / 4 counters, one per 128-byte
+// line, zero between launches (the kernel resets what it used).  Launches that may run concurrently must not share a set,
+// so every context keeps one set per stream it has been used with; launches on one stream are ordered.
+struct rd_tickets {
+    std::mutex mu;
+    std::map<hipStream_t, uint32_t *> sets;
+    static constexpr size_t bytes = (size_t)(RD_MAX_BLOCKS / 4) * RD_TQ_STRIDE * sizeof(uint32_t);
+    uint32_t *get(hipStream_t s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = sets.find(s);
+        if (it != sets.end()) return it->second;
+        uint32_t *d = nullptr;
+        if (hipMalloc((void **)&d, bytes) != hipSuccess) return nullptr;
+        if (hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(d); return nullptr; }
+        sets[s] = d;
+        return d;
+    }
+    void release()                   // caller has synchronised the device
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : sets) (void)hipFree(kv.second);
+        sets.clear();
+    }
+};
+
 template <int FMT, bool HIST, int MATH>
 static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t unit0,
                               uint32_t unit1, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
-                              unsigned long long *slab64, hipStream_t s)
+                              unsigned long long *slab64, uint32_t *tq, hipStream_t s)
 {
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
+    const uint32_t tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;   // rd_kernels.h: split()
     const uint32_t nwaves = blocks * RD_WAVES;
+    const uint32_t ntiles = (unit1 - unit0) * tpu;
+    // ticket counters: groups of RD_TQ_CLIENTS waves need gridDim % 16 == 0 (rd_blocks_for rounds to that); else one counter
+    static const bool static_deal = rd_env_u32("RD_STATIC_DEAL", 0) != 0;                 // A/B switch: no tickets
+    const uint32_t tq_k = static_deal ? 0u : (blocks >= 16u && blocks % 16u == 0u) ? blocks / 4u : 1u;
+    const uint32_t ndyn = ntiles > nwaves ? ntiles - nwaves : 0u;
+    const uint32_t tq_tmax = tq_k ? (ndyn + tq_k - 1u) / tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;   // A/B override: 0 / 1
     // read burst (rd_kernels.h): f32 surface by default; needs 16-byte aligned CFA rows and a launch worth it
     const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
@@ -156,16 +190,16 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     if constexpr (FMT == RD_FMT_RGBA_F32) {     // the burst variant exists for the f32 surface only
         if (W % 128u == 0 && burst) {
             hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                               unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+                               unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u, slab32, slab64);
             return;
         }
     }
     if (W % 128u == 0)
         hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                           unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+                           unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u, slab32, slab64);
     else
         hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                           unit0, unit1, tpu, nwaves / tpu, nwaves % tpu, u, slab32, slab64);
+                           unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u, slab32, slab64);
 }
 
 template <int FMT, bool HIST, int MATH>
@@ -201,6 +235,7 @@ static uint32_t rd_blocks_for(const rd_launch_cfg &cfg, uint64_t items, bool his
     uint64_t cap = (uint64_t)cfg.n_cu * (hist ? cfg.wg_per_cu_hist : cfg.wg_per_cu_plain);
     if (cap > RD_MAX_BLOCKS) cap = RD_MAX_BLOCKS;
     uint64_t b = need < cap ? need : cap;
+    if (b >= 16u) b &= ~(uint64_t)15u;           // whole groups of ticket-counter clients (rd_launch_quads_t)
     return b ? (uint32_t)b : 1u;
 }
 
@@ -212,14 +247,16 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
                              uint32_t tw, uint32_t th, uint32_t fmt, void *out, const rd_ku &u,
                              bool use_quads, uint32_t unit0, uint32_t unit1, bool hist, uint32_t math,
                              uint32_t *slab32, unsigned long long *slab64, uint32_t fixed_blocks,
-                             hipStream_t s, uint32_t *blocks_out)
+                             rd_tickets &tickets, hipStream_t s, uint32_t *blocks_out)
 {
     uint32_t blocks;
     if (use_quads) {
+        uint32_t *tq = tickets.get(s);
+        if (!tq) return rd_fail(RD_ERR_OOM, "ticket counter allocation failed");
         const uint64_t items = (uint64_t)(unit1 - unit0) * (((W >> 1) + 63u) / 64u) * 64u;   // lanes
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
-        RD_DISPATCH(rd_launch_quads_t, fmt, hist, math, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, s);
+        RD_DISPATCH(rd_launch_quads_t, fmt, hist, math, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, tq, s);
     } else {
         const uint64_t items = (uint64_t)tw * th;
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "target too large for 32-bit pixel index");
@@ -251,6 +288,7 @@ struct rd_pipeline {
     void *out_buf = nullptr; size_t out_cap = 0;
     uint32_t *slab32 = nullptr;       // RD_MAX_BLOCKS x 768
     uint32_t *hist_dev = nullptr;     // 768
+    rd_tickets tickets;
     std::mutex mu;                    // uniforms + scratch (Send + Sync like Arc<RenderPipeline>)
 };
 
@@ -330,6 +368,8 @@ extern "C" void rd_pipeline_destroy(rd_pipeline *p)
         if (p->out_buf) (void)hipFree(p->out_buf);
         if (p->slab32) (void)hipFree(p->slab32);
         if (p->hist_dev) (void)hipFree(p->hist_dev);
+        (void)hipDeviceSynchronize();        // renders enqueued on caller streams (rd_render_device) may still draw tickets
+        p->tickets.release();
     }
     delete p;
 }
@@ -387,7 +427,7 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
                        (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
     uint32_t blocks = 0;
     int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
-                               hist_dev != nullptr, p->math_mode, p->slab32, nullptr, 0, s, &blocks);
+                               hist_dev != nullptr, p->math_mode, p->slab32, nullptr, 0, p->tickets, s, &blocks);
     if (rc) return rc;
     if (hist_dev) {
         hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, s, p->slab32, blocks, hist_dev);
@@ -487,6 +527,7 @@ struct rd_batch {
     rd_launch_cfg cfg;
     uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
     unsigned long long *slab64 = nullptr;      // blocks x 768
+    rd_tickets tickets;
 };
 
 extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
@@ -527,7 +568,9 @@ extern "C" void rd_batch_destroy(rd_batch *b)
     if (!b) return;
     {
         rd_devguard g(b->device);
-        if (b->slab64) { (void)hipDeviceSynchronize(); (void)hipFree(b->slab64); }
+        (void)hipDeviceSynchronize();        // launches on the caller's streams still use the slab and the tickets
+        if (b->slab64) (void)hipFree(b->slab64);
+        b->tickets.release();
     }
     delete b;
 }
@@ -559,8 +602,8 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
             const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
             const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
             int rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0,
-                                       u1, b->hist, b->math_mode, nullptr, b->slab64, b->blocks, (hipStream_t)stream,
-                                       nullptr);
+                                       u1, b->hist, b->math_mode, nullptr, b->slab64, b->blocks, b->tickets,
+                                       (hipStream_t)stream, nullptr);
             if (rc) return rc;
         }
     }
@@ -596,6 +639,7 @@ struct rd_exporter {
     rd_launch_cfg cfg;
     hipStream_t compute = nullptr, copy = nullptr;
     rd_export_slot *slots = nullptr;
+    rd_tickets tickets;
     std::mutex mu;
 };
 
@@ -614,6 +658,7 @@ extern "C" void rd_exporter_destroy(rd_exporter *e)
         }
         if (e->compute) (void)hipStreamDestroy(e->compute);
         if (e->copy) (void)hipStreamDestroy(e->copy);
+        e->tickets.release();
     }
     delete[] e->slots;
     delete e;
@@ -674,7 +719,7 @@ extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *
     if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
     const rd_ku u = rd_make_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode);
     int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
-                               e->math_mode, nullptr, nullptr, 0, e->compute, nullptr);
+                               e->math_mode, nullptr, nullptr, 0, e->tickets, e->compute, nullptr);
     if (rc) return rc;
     RD_HIP(hipEventRecord(s.kernel_done, e->compute));
     RD_HIP(hipStreamWaitEvent(e->copy, s.kernel_done, 0));

@@ -226,11 +226,24 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 //     row b (py even), column 2q+1  : (r,g,b) = (C, D, B)
 // Requires W even and cfa 4-byte aligned (the host falls back to rd_develop_map otherwise).
 //
-// Scheduling: a WAVE owns a tile = 64 consecutive quads of one unit (128 px x 2 rows); tiles are
-// dealt round-robin to the resident waves.  Tile bookkeeping (unit, tile-in-unit, row bases) is
-// wave-uniform and lives in SGPRs/SALU; per-lane integer work is one lane offset.  The next
-// tile's two loads (256 B per row per wave) are issued before the current tile's arithmetic and
-// stores, so a load never waits behind a younger store in the in-order vmcnt queue.
+// Scheduling: a WAVE owns a tile = 64 consecutive quads of one unit (128 px x 2 rows).  Every wave
+// starts on tile `slot` (static) and then draws further tiles from a ticket counter with a SCALAR
+// atomic (s_atomic_add: returns through lgkmcnt into an SGPR, so it neither occupies a lane nor a
+// place in the in-order vmcnt queue the loads and stores live in).  Why not static round-robin:
+// measured per-workgroup timelines (tools/microbench.hip, MB_TIMELINE) show that of the two
+// workgroups sharing a CU the first-dispatched one runs ~1.6x faster (older waves win arbitration)
+// and that the XCDs differ by 5-8 % -- with a static deal the CU then runs half-empty for the last
+// third of the launch.  One address serves only ~88 M atomics/s (11.4 ns each, tools/atomic_probe.hip),
+// so the tickets are spread over K = gridDim/4 counters of 64 client waves each; counter k deals the
+// tiles nwaves + t*K + k (interleaved, so all counters advance together and the launch keeps ONE
+// moving front through the frame), and its 64 clients are picked across all XCDs, both workgroups
+// of a CU and four wave slots, so every group drains at the chip's average speed and no stealing
+// is needed.  Every client ends with exactly one failed draw, so a counter's final value is known
+// (tmax + clients) and the wave that draws it resets the counter for the next launch.
+// Tile bookkeeping (unit, tile-in-unit, row bases) is wave-uniform and lives in SGPRs/SALU; per-lane
+// integer work is one lane offset.  The next tile's two loads (256 B per row per wave) are issued
+// before the current tile's arithmetic and stores, so a load never waits behind a younger store in
+// the in-order vmcnt queue.
 //
 // Stores: a lane's two f32 pixels are 32 B, so storing them directly gives every store
 // instruction a 32-B lane stride (half-used 64-B requests; measured 2.4 TB/s when store-bound).
@@ -239,6 +252,12 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // (16 B per lane per row) and u8 (8 B) are contiguous as they are and skip the transpose.
 // ---------------------------------------------------------------------------------------------
 #define RD_WAVES (RD_BLOCK / 64)
+#define RD_TQ_STRIDE 32u        // dwords between ticket counters (128 B: one counter per cache line)
+#define RD_TQ_CLIENTS 64u       // waves per counter when the launch uses more than one
+// Two 1024-thread workgroups fit a CU only while a wave needs <= 80 SGPRs (800 per SIMD, 16-register granules and a
+// 16-register trap-handler reserve per wave: 96 + 16 allows 7 waves per SIMD, not 8).  hipcc reports "occupancy 8" either
+// way; with 83 SGPRs the second workgroup of every CU was measured to start only when the first had finished (+12 %).
+#define RD_NUM_SGPR 80
 #ifdef RD_COLOUR_HOOK_HEADER  // tools/microbench.hip only: swaps in reduced-VALU stand-ins to find the memory floor
 #include RD_COLOUR_HOOK_HEADER
 #endif
@@ -262,30 +281,68 @@ template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c
 template <> struct rd_tile_out<RD_FMT_RGBA_U8> { uint32_t v1, v2, v3; };
 template <> struct rd_tile_out<RD_FMT_RGB_U8> { uint32_t v1, v2, v3; };                   // 0x00bbggrr
 
+#ifdef RD_PROBE   // tools/microbench.hip only: per-workgroup timeline (100 MHz ticks, shader-clock ticks, HW_ID, XCC_ID, tiles)
+__device__ uint32_t rd_probe_buf[RD_MAX_BLOCKS * 8];
+#endif
+
 template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
-__global__ void __launch_bounds__(RD_BLOCK)
+__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
-                 uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t step_units,
-                 uint32_t step_rem, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
+                 uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k,
+                 uint32_t tq_tmax, uint32_t *tq, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
 {
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[(FMT == RD_FMT_RGBA_F32 || BURST) ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     if (HIST) rd_hist_zero(lh);
+#ifdef RD_PROBE
+    const uint64_t probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t probe_tiles = 0;
+    if (threadIdx.x == 0) rd_probe_buf[blockIdx.x * 8u + 6u] = 0u;
+#endif
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qpr = W >> 1;                                 // quads per unit
     const uint32_t ntiles = (unit1 - unit0) * tpu;               // < 2^32: checked on the host
-    const uint32_t nwaves = gridDim.x * RD_WAVES;                // == step_units*tpu + step_rem
+    const uint32_t nwaves = gridDim.x * RD_WAVES;
     const uint32_t copy = lane & (RD_HK - 1);
-    // Wave -> slot is block-cyclic (slot = wave_in_block * gridDim + block): in the last, partial round of
-    // tiles the busy slots are then spread evenly over all workgroups, i.e. over all CUs.  With the
-    // block-major order the first 53 % of the workgroups got one tile more per wave (+4 % on the heaviest CU).
+    // First tile: static, slot = wave_in_block * gridDim + block (block-cyclic, so a launch smaller than the grid is
+    // spread over all CUs).
     uint32_t tile = wave * gridDim.x + blockIdx.x;
-    uint32_t unit = unit0 + tile / tpu;
-    uint32_t qt = tile % tpu;
+
+    // tile -> (unit, tile in unit) without a divide: q = mulhi(t, floor(2^32 / tpu)) is floor(t / tpu) or one less.
+    auto split = [&](uint32_t t, uint32_t &un, uint32_t &q) {
+        uint32_t d = __umulhi(t, tpu_magic);
+        uint32_t r = t - d * tpu;
+        if (r >= tpu) { d += 1u; r -= tpu; }
+        un = unit0 + d; q = r;
+    };
+    // Ticket counter of this wave's group (see the header comment).  tq_k == 1: one counter for the whole launch.
+    const uint32_t tq_clients = tq_k > 1u ? RD_TQ_CLIENTS : nwaves;
+    const uint32_t tq_idx = tq_k > 1u ? (wave & 3u) * (gridDim.x >> 4) + ((blockIdx.x >= (gridDim.x >> 1) ? blockIdx.x - (gridDim.x >> 1) : blockIdx.x) >> 3) : 0u;
+    uint32_t *const tq_cnt = tq + (size_t)tq_idx * RD_TQ_STRIDE;
+    // Next tile of this wave, or ~0u when its counter is exhausted (every wave gets that answer exactly once).
+    uint32_t dealt = tile;                                       // tq_k == 0 (A/B switch RD_STATIC_DEAL=1): static round-robin deal
+    auto draw = [&]() -> uint32_t {
+        if (tq_k == 0u) { dealt += nwaves; return dealt < ntiles ? dealt : ~0u; }
+        for (;;) {
+            uint32_t t = 1u;
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(tq_cnt) : "memory");
+            if (t >= tq_tmax) {
+                if (t == tq_tmax + tq_clients - 1u) {            // last draw on this counter in this launch: reset it
+                    uint32_t z = 0u;
+                    asm volatile("s_atomic_and %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(z) : "s"(tq_cnt) : "memory");
+                }
+                return ~0u;
+            }
+            t = nwaves + t * tq_k + tq_idx;
+            if (t < ntiles) return t;                            // only ticket tmax-1 can point past the end
+        }
+    };
+    uint32_t unit, qt;
+    split(tile, unit, qt);
 
     // cfa[ra][2q..2q+1] and cfa[rb][2q..2q+1] of tile (pu, pq) for this lane; rows clamped to the image.
     auto load_tile = [&](uint32_t pu, uint32_t pq, uint32_t &top, uint32_t &bot) {
@@ -466,7 +523,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
                 const uint32_t *pt = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W) + q;
                 const uint32_t *pb = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W) + q;
                 const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
-                    (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(stage + (size_t)wave * 192u));
+                    (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&stage[0]) + wave * (192u * 16u));
                 const rd_u4 *a[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -507,29 +564,45 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
         //   iteration i:  issue loads(i+1) | store tile i-1 (registers -> LDS transpose -> HBM) | compute tile i
         // vmcnt retires in order, so waiting for loads(i+1) only requires the stores of tile i-2 to
         // have completed; the stores of tile i-1 overlap this wave's own arithmetic.
-        uint32_t ntile = tile + nwaves;
-        uint32_t nunit = unit + step_units, nqt = qt + step_rem;
-        if (nqt >= tpu) { nqt -= tpu; nunit += 1u; }
-        bool more = ntile < ntiles;
+        uint32_t ntile = draw();
+        bool more = ntile != ~0u;
+        uint32_t nunit = unit, nqt = qt;
+        if (more) split(ntile, nunit, nqt);
         uint32_t ntop, nbot;
-        load_tile(more ? nunit : unit, more ? nqt : qt, ntop, nbot);
+        load_tile(nunit, nqt, ntop, nbot);
         rd_tile_out<FMT> pend = compute_tile(unit, qt, top, bot);
         uint32_t punit = unit, pqt = qt;
         asm volatile("" : "+v"(ntop), "+v"(nbot));               // same reason: nothing pending at the loop header
         while (more) {
-            tile = ntile; unit = nunit; qt = nqt; top = ntop; bot = nbot;
-            ntile = tile + nwaves;
-            nunit = unit + step_units; nqt = qt + step_rem;
-            if (nqt >= tpu) { nqt -= tpu; nunit += 1u; }
-            more = ntile < ntiles;
-            load_tile(more ? nunit : unit, more ? nqt : qt, ntop, nbot);   // unconditional (last pass re-reads its own)
+#ifdef RD_PROBE
+            ++probe_tiles;
+#endif
+            unit = nunit; qt = nqt; top = ntop; bot = nbot;
+            ntile = draw();
+            more = ntile != ~0u;
+            if (more) split(ntile, nunit, nqt);
+            load_tile(nunit, nqt, ntop, nbot);                   // unconditional (the last pass re-reads its own)
             store_tile(punit, pqt, pend);
             pend = compute_tile(unit, qt, top, bot);
             punit = unit; pqt = qt;
         }
         store_tile(punit, pqt, pend);
+    } else {
+        (void)draw();                                            // launch smaller than the grid: still one (failed) draw per wave
     }
     if (HIST) rd_hist_flush(lh, slab32, slab64);
+#ifdef RD_PROBE
+    if (lane == 0) atomicAdd(&rd_probe_buf[blockIdx.x * 8u + 6u], probe_tiles + (tile < ntiles ? 1u : 0u));
+    if (threadIdx.x == 0) {
+        const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        rd_probe_buf[blockIdx.x * 8u + 0u] = (uint32_t)(t1 - probe_t0);
+        rd_probe_buf[blockIdx.x * 8u + 1u] = (uint32_t)(r1 - probe_r0);
+        rd_probe_buf[blockIdx.x * 8u + 2u] = (uint32_t)probe_r0;
+        rd_probe_buf[blockIdx.x * 8u + 3u] = (uint32_t)r1;
+        rd_probe_buf[blockIdx.x * 8u + 4u] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+        rd_probe_buf[blockIdx.x * 8u + 5u] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

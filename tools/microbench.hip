@@ -347,18 +347,27 @@ int main(int argc, char **argv)
     ADD("store+hist nt 1024x256", M_STORE | M_HIST, 1024, 256);
     unsigned long long *slab64; CK(hipMalloc((void **)&slab64, (size_t)RD_MAX_BLOCKS * 768 * 8)); CK(hipMemset(slab64, 0, (size_t)RD_MAX_BLOCKS * 768 * 8));
     const uint32_t tpu = (qpr + 63) / 64;
+    uint32_t *tq; CK(hipMalloc((void **)&tq, 256 * 128)); CK(hipMemset(tq, 0, 256 * 128));   // ticket counters
 #ifndef MATHMODE
 #define MATHMODE 0
 #endif
-#define PROD(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                   \
-    vs.push_back({ NAME, [&, qpr, tpu](int k) { const uint32_t nw = (BLOCKS) * RD_WAVES;               \
+#define PRODS(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                  \
+    vs.push_back({ NAME, [&, qpr, tpu](int k) {                                                         \
         hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
-                           W, H, 0u, H / 2 + 1, tpu, nw / tpu, nw % tpu, u, S32, S64); }, {} })
+                           W, H, 0u, H / 2 + 1, tpu, (uint32_t)((1ull << 32) / tpu), 0u, 0u, tq, u, S32, S64); }, {} })
+#define PROD(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                   \
+    vs.push_back({ NAME, [&, qpr, tpu](int k) { const uint32_t nw = (BLOCKS) * RD_WAVES, nt = (H / 2 + 1) * tpu;  \
+        const uint32_t tk = ((BLOCKS) % 16 == 0) ? (BLOCKS) / 4 : 1, tmax = (nt - nw + tk - 1) / tk;     \
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
+                           W, H, 0u, H / 2 + 1, tpu, (uint32_t)((1ull << 32) / tpu), tk, tmax, tq, u, S32, S64); }, {} })
     PROD("PRODUCT f32 hist slab32 x256", 0, true, 256, false, slab, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 hist slab64 x256", 0, true, 256, false, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f32 hist slab64 x256 BURST", 0, true, 256, true, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f32 hist slab64 x512", 0, true, 512, false, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f32 hist slab64 x512 BURST", 0, true, 512, true, (uint32_t *)nullptr, slab64);
+    PRODS("STATIC  f32 hist slab64 x512 BURST", 0, true, 512, true, (uint32_t *)nullptr, slab64);
+    PRODS("STATIC  f32 nohist x512 BURST", 0, false, 512, true, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    PRODS("STATIC  u8 hist x256", 2, true, 256, false, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f32 nohist x256", 0, false, 256, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 nohist x512", 0, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 nohist x512 BURST", 0, false, 512, true, (uint32_t *)nullptr, (unsigned long long *)nullptr);
@@ -438,6 +447,31 @@ int main(int argc, char **argv)
             }
         }
     }
+#ifdef RD_PROBE
+    {   // per-workgroup timeline of the product kernel: s_memtime (shader clock) against s_memrealtime (100 MHz), HW_ID, tiles
+        const uint32_t nw = 512 * RD_WAVES, nt = (H / 2 + 1) * tpu, tk = 128, tmax = (nt - nw + tk - 1) / tk;
+        std::vector<uint32_t> hc(512 * 8);
+        const int nrep = getenv("MB_CLOCK_REPS") ? atoi(getenv("MB_CLOCK_REPS")) : 3;
+        for (int rep = 0; rep < nrep; ++rep) {
+            for (int k = 0; k < 256; ++k)
+                hipLaunchKernelGGL((rd_develop_quads<0, true, true, MATHMODE, true>), dim3(512), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT],
+                                   W, H, 0u, H / 2 + 1, tpu, (uint32_t)((1ull << 32) / tpu), tk, tmax, tq, u, (uint32_t *)nullptr, slab64);
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpyFromSymbol(hc.data(), HIP_SYMBOL(rd_probe_buf), 512 * 8 * 4));
+            double st = 0, sr = 0, mx = 0; uint32_t t_min = 0xffffffffu, tl_min = ~0u, tl_max = 0, tl_sum = 0;
+            for (int b = 0; b < 512; ++b) {
+                st += hc[8 * b]; sr += hc[8 * b + 1]; mx = std::max(mx, (double)hc[8 * b + 1]); t_min = std::min(t_min, hc[8 * b + 2]);
+                tl_min = std::min(tl_min, hc[8 * b + 6]); tl_max = std::max(tl_max, hc[8 * b + 6]); tl_sum += hc[8 * b + 6];
+            }
+            printf("probe: workgroup mean %.1f us, longest %.1f us, shader clock %.0f MHz, tiles per workgroup %u..%u (sum %u of %u)\n",
+                   sr / 512 / 100, mx / 100, st / sr * 100, tl_min, tl_max, tl_sum, nt);
+            if (rep == nrep - 1 && getenv("MB_TIMELINE"))
+                for (int b = 0; b < 512; ++b)
+                    printf("wg %3d start %7.2f end %7.2f us  hw_id %08x xcc %x  cu %2u sh %u se %u tiles %u\n", b, (hc[8 * b + 2] - t_min) / 100.0, (hc[8 * b + 3] - t_min) / 100.0,
+                           hc[8 * b + 4], hc[8 * b + 5], (hc[8 * b + 4] >> 8) & 15u, (hc[8 * b + 4] >> 12) & 1u, (hc[8 * b + 4] >> 13) & 7u, hc[8 * b + 6]);
+        }
+    }
+#endif
     if (argc > 2) {   // sustained run of the full kernel: burst vs throttled clock
         auto &v = vs[16];   // PRODUCT f32 hist slab64
         for (int w = 0; w < atoi(argv[2]); ++w) {
@@ -445,6 +479,13 @@ int main(int argc, char **argv)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("sustained window %2d: %.1f us per launch\n", w, ms * 1e3 / 256);
         }
+    }
+    if (const char *only = getenv("MB_ONLY")) {          // keep variants whose name contains one of the '|'-separated substrings
+        std::vector<std::string> keys; std::string cur;
+        for (const char *c = only;; ++c) { if (*c == '|' || !*c) { if (!cur.empty()) keys.push_back(cur); cur.clear(); if (!*c) break; } else cur += *c; }
+        std::vector<Variant> keep;
+        for (auto &v : vs) for (auto &k : keys) if (v.name.find(k) != std::string::npos) { keep.push_back(v); break; }
+        vs.swap(keep);
     }
     for (int r = -1; r < ROUNDS; ++r) {
         for (auto &v : vs) {
