@@ -23,7 +23,7 @@
 #include "rd_math.h"
 #include "rd_uniforms.h"
 
-#define RD_BLOCK 1024       // 16 waves: one workgroup per CU, 4 waves per SIMD
+#define RD_BLOCK 1024       // 16 waves; two workgroups per CU = 8 waves per SIMD
 #define RD_MAX_BLOCKS 1024  // slab capacity (workgroups per launch)
 #ifndef RD_HK
 #define RD_HK 8             // private histogram copies per bin: lane l adds into copy l % RD_HK
