@@ -526,7 +526,14 @@ struct rd_batch {
     uint32_t math_mode = RD_MATH_STRICT;
     rd_launch_cfg cfg;
     uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
-    unsigned long long *slab64 = nullptr;      // blocks x 768
+    // RD_BATCH_STREAMS=2: launches alternate between the caller's stream and an internal one (forked from and joined back
+    // into the caller's stream inside rd_batch_develop), so the next frame's workgroups move in as the previous frame's
+    // finish.  Concurrent launches need their own slab rows and ticket counters.  Measured +2.4 % (strict) / -2 %
+    // (contracted) on 256 x 24 MP: not the default.
+    uint32_t n_streams = 1;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long *slab64 = nullptr;      // n_streams x blocks x 768
     rd_tickets tickets;
 };
 
@@ -554,10 +561,22 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
     if (!b->identity_ok) { delete b; return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h); }
     b->blocks = rd_blocks_for(b->cfg, items, b->hist);
-    if (b->hist) {
-        hipError_t e = hipMalloc((void **)&b->slab64, (size_t)b->blocks * 768 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(b->slab64, 0, (size_t)b->blocks * 768 * sizeof(unsigned long long));
-        if (e != hipSuccess) { delete b; return rd_fail(RD_ERR_OOM, "slab allocation failed: %s", hipGetErrorString(e)); }
+    b->n_streams = rd_env_u32("RD_BATCH_STREAMS", 1) >= 2 ? 2u : 1u;
+    hipError_t e = hipSuccess;
+    if (b->n_streams > 1) {
+        e = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+    }
+    if (e == hipSuccess && b->hist) {
+        const size_t bytes = (size_t)b->n_streams * b->blocks * 768 * sizeof(unsigned long long);
+        e = hipMalloc((void **)&b->slab64, bytes);
+        if (e == hipSuccess) e = hipMemset(b->slab64, 0, bytes);
+    }
+    if (e != hipSuccess) {
+        const int code = rd_fail(RD_ERR_OOM, "batch resources: %s", hipGetErrorString(e));
+        rd_batch_destroy(b);
+        return code;
     }
     *out = b;
     return RD_OK;
@@ -571,6 +590,9 @@ extern "C" void rd_batch_destroy(rd_batch *b)
         (void)hipDeviceSynchronize();        // launches on the caller's streams still use the slab and the tickets
         if (b->slab64) (void)hipFree(b->slab64);
         b->tickets.release();
+        if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+        if (b->aux) (void)hipStreamDestroy(b->aux);
     }
     delete b;
 }
@@ -591,23 +613,36 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
     const uint32_t units = b->h / 2u + 1u;
     uint32_t bands = row_bands ? row_bands : 1u;
     if (bands > units) bands = units;
-    for (size_t f = 0; f < n; ++f) {
+    hipStream_t lanes[2] = { (hipStream_t)stream, (hipStream_t)stream };
+    const bool fork = b->n_streams > 1 && (uint64_t)n * bands > 1u;
+    if (fork) {
+        RD_HIP(hipEventRecord(b->ev_fork, lanes[0]));
+        RD_HIP(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
+        lanes[1] = b->aux;
+    }
+    int rc = RD_OK;
+    size_t launch = 0;
+    for (size_t f = 0; f < n && rc == RD_OK; ++f) {
         const rd_frame &fr = frames[f];
-        if (!fr.cfa_dev || !fr.out_dev) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f);
-        if ((uintptr_t)fr.cfa_dev % 4u) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f);
-        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f);
+        if (!fr.cfa_dev || !fr.out_dev) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f); break; }
+        if ((uintptr_t)fr.cfa_dev % 4u) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f); break; }
+        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f); break; }
         const rd_ku u = rd_make_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level,
                                    b->math_mode);
-        for (uint32_t k = 0; k < bands; ++k) {
+        for (uint32_t k = 0; k < bands && rc == RD_OK; ++k, ++launch) {
             const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
             const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
-            int rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0,
-                                       u1, b->hist, b->math_mode, nullptr, b->slab64, b->blocks, b->tickets,
-                                       (hipStream_t)stream, nullptr);
-            if (rc) return rc;
+            const size_t lane = fork ? (launch & 1u) : 0u;
+            unsigned long long *slab = b->slab64 ? b->slab64 + lane * (size_t)b->blocks * 768u : nullptr;
+            rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0, u1,
+                                   b->hist, b->math_mode, nullptr, slab, b->blocks, b->tickets, lanes[lane], nullptr);
         }
     }
-    return RD_OK;
+    if (fork) {                                  // join even after an error: what was enqueued stays ordered
+        RD_HIP(hipEventRecord(b->ev_join, b->aux));
+        RD_HIP(hipStreamWaitEvent(lanes[0], b->ev_join, 0));
+    }
+    return rc;
 }
 
 extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
@@ -616,8 +651,8 @@ extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
     if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
-    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(256), 0, (hipStream_t)stream, b->slab64, b->blocks,
-                       (unsigned long long *)hist_dev);
+    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(256), 0, (hipStream_t)stream, b->slab64,
+                       b->blocks * b->n_streams, (unsigned long long *)hist_dev);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

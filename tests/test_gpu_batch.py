@@ -75,6 +75,19 @@ def test_batch_mid_size_frames(gpu_lib, refc):
     _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F16, 4)
 
 
+def test_batch_ticket_scheduling(gpu_lib, refc, monkeypatch):
+    """More tiles than resident waves (3008 x 2008: 24 120 tiles against 8192 waves), so most tiles are dealt by the
+    ticket counters; repeated launches (the counters must come back to zero), row bands and the optional two-stream
+    issue all give the oracle's bits and the same histogram."""
+    ra = gpu_lib
+    _run_batch(ra, refc, 2008, 3008, 2, ra.FMT_RGBA_F32, 1)
+    _run_batch(ra, refc, 2008, 3008, 2, ra.FMT_RGBA_U8, 3)
+    monkeypatch.setenv("RD_BATCH_STREAMS", "2")
+    _run_batch(ra, refc, 2008, 3008, 3, ra.FMT_RGBA_F16, 2)
+    _run_batch(ra, refc, 34, 48, 5, ra.FMT_RGBA_F32, 3)
+    monkeypatch.delenv("RD_BATCH_STREAMS")
+
+
 def test_batch_contracted_math(gpu_lib, refc):
     ra = gpu_lib
     _run_batch(ra, refc, 34, 256, 3, ra.FMT_RGBA_F32, 2, math=ra.MATH_CONTRACTED)
