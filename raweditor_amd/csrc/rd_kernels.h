@@ -23,7 +23,9 @@
 #include "rd_math.h"
 #include "rd_uniforms.h"
 
-#define RD_BLOCK 1024       // 16 waves; two workgroups per CU = 8 waves per SIMD
+#ifndef RD_BLOCK
+#define RD_BLOCK 1024       // 16 waves; two workgroups per CU = 8 waves per SIMD (tools/microbench.hip may override)
+#endif
 #define RD_MAX_BLOCKS 1024  // slab capacity (workgroups per launch)
 #ifndef RD_HK
 #define RD_HK 8             // private histogram copies per bin: lane l adds into copy l % RD_HK
@@ -253,11 +255,13 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // ---------------------------------------------------------------------------------------------
 #define RD_WAVES (RD_BLOCK / 64)
 #define RD_TQ_STRIDE 32u        // dwords between ticket counters (128 B: one counter per cache line)
-#define RD_TQ_CLIENTS 64u       // waves per counter when the launch uses more than one
+#define RD_TQ_CLIENTS (RD_WAVES * 4u)   // waves per counter when the launch uses more than one (needs RD_WAVES % 4 == 0)
 // Two 1024-thread workgroups fit a CU only while a wave needs <= 80 SGPRs (800 per SIMD, 16-register granules and a
 // 16-register trap-handler reserve per wave: 96 + 16 allows 7 waves per SIMD, not 8).  hipcc reports "occupancy 8" either
 // way; with 83 SGPRs the second workgroup of every CU was measured to start only when the first had finished (+12 %).
+#ifndef RD_NUM_SGPR
 #define RD_NUM_SGPR 80
+#endif
 #ifdef RD_COLOUR_HOOK_HEADER  // tools/microbench.hip only: swaps in reduced-VALU stand-ins to find the memory floor
 #include RD_COLOUR_HOOK_HEADER
 #endif

@@ -353,12 +353,12 @@ int main(int argc, char **argv)
 #endif
 #define PRODS(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                  \
     vs.push_back({ NAME, [&, qpr, tpu](int k) {                                                         \
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(RD_BLOCK), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
                            W, H, 0u, H / 2 + 1, tpu, (uint32_t)((1ull << 32) / tpu), 0u, 0u, tq, u, S32, S64); }, {} })
 #define PROD(NAME, FMT, HIST, BLOCKS, BURST, S32, S64)                                                   \
     vs.push_back({ NAME, [&, qpr, tpu](int k) { const uint32_t nw = (BLOCKS) * RD_WAVES, nt = (H / 2 + 1) * tpu;  \
         const uint32_t tk = ((BLOCKS) % 16 == 0) ? (BLOCKS) / 4 : 1, tmax = (nt - nw + tk - 1) / tk;     \
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
+        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATHMODE, BURST>), dim3(BLOCKS), dim3(RD_BLOCK), 0, s, din[k % NIN], (void *)dout[k % NOUT], \
                            W, H, 0u, H / 2 + 1, tpu, (uint32_t)((1ull << 32) / tpu), tk, tmax, tq, u, S32, S64); }, {} })
     PROD("PRODUCT f32 hist slab32 x256", 0, true, 256, false, slab, (unsigned long long *)nullptr);
     PROD("PRODUCT f32 hist slab64 x256", 0, true, 256, false, (uint32_t *)nullptr, slab64);
@@ -454,7 +454,7 @@ int main(int argc, char **argv)
         const int nrep = getenv("MB_CLOCK_REPS") ? atoi(getenv("MB_CLOCK_REPS")) : 3;
         for (int rep = 0; rep < nrep; ++rep) {
             for (int k = 0; k < 256; ++k)
-                hipLaunchKernelGGL((rd_develop_quads<0, true, true, MATHMODE, true>), dim3(512), dim3(1024), 0, s, din[k % NIN], (void *)dout[k % NOUT],
+                hipLaunchKernelGGL((rd_develop_quads<0, true, true, MATHMODE, true>), dim3(512), dim3(RD_BLOCK), 0, s, din[k % NIN], (void *)dout[k % NOUT],
                                    W, H, 0u, H / 2 + 1, tpu, (uint32_t)((1ull << 32) / tpu), tk, tmax, tq, u, (uint32_t *)nullptr, slab64);
             CK(hipStreamSynchronize(s));
             CK(hipMemcpyFromSymbol(hc.data(), HIP_SYMBOL(rd_probe_buf), 512 * 8 * 4));

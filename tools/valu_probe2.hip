@@ -1,0 +1,77 @@
+// tools/valu_probe2.hip -- VALU issue rate of scalar f32 ops by operand kind (VGPR / SGPR / literal / inline constant).
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -o tools/valu_probe2 tools/valu_probe2.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// KIND: 0 fma v,v,v   1 fma s,v,v (one SGPR)   2 fmaak (literal addend)   3 fma v,v,1.0 (inline const)
+//       4 mul v,v     5 mul s,v                6 mul literal,v            7 add v,v   8 add s,v   9 fmac v,v (VOP2, 4 bytes)
+//      10 fma v,s,s (same SGPR twice)         11 max v,v                12 cvt_f32_u32        13 mul_f32 then add (2 ops all vgpr)
+template <int KIND, int ILP>
+__global__ void __launch_bounds__(1024) k(float *out, float a, float b, int iters)
+{
+    float av = a, bv = b;
+    asm volatile("" : "+v"(av), "+v"(bv));
+    float x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) x[i] = (float)(threadIdx.x + i) * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < ILP; ++i) {
+                float &v = x[i];
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 1) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(v) : "s"(a), "v"(bv));
+                if (KIND == 2) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3a83126f" : "+v"(v) : "v"(av));
+                if (KIND == 3) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(v) : "v"(av));
+                if (KIND == 4) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(v) : "v"(av));
+                if (KIND == 5) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(v) : "s"(a));
+                if (KIND == 6) asm volatile("v_mul_f32_e32 %0, 0x3f7fbe77, %0" : "+v"(v));
+                if (KIND == 7) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 8) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(v) : "s"(b));
+                if (KIND == 9) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 10) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v) : "s"(a));
+                if (KIND == 11) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 12) asm volatile("v_cvt_f32_u32_e32 %0, %0" : "+v"(v));
+                if (KIND == 13) asm volatile("v_mul_f32_e32 %0, %0, %1\n\tv_add_f32_e32 %0, %0, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 14) asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 15) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v) : "v"(bv));
+                if (KIND == 16) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 17) asm volatile("v_rndne_f32_e32 %0, %0" : "+v"(v));
+            }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += x[i];
+    if (s == 1234.5678f) out[0] = s;
+}
+
+template <int KIND, int ILP>
+static void run(const char *name, float *out)
+{
+    const int iters = 512, blocks = 512;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k<KIND, ILP>), dim3(blocks), dim3(1024), 0, 0, out, 0.999f, 0.001f, iters);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL((k<KIND, ILP>), dim3(blocks), dim3(1024), 0, 0, out, 0.999f, 0.001f, iters);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 4;
+    const double instr = (double)blocks * 16 * ILP * 4 * iters * (KIND == 13 ? 2 : 1);     // wave-instructions
+    printf("%-40s ILP %2d: %8.1f us  %6.2f ns per wave-instr per SIMD  (%5.2f T lane-op/s)\n", name, ILP, ms * 1e3,
+           ms * 1e6 / (instr / 1024), instr * 64 / (ms * 1e-3) / 1e12);
+}
+
+int main()
+{
+    float *out; CK(hipMalloc((void **)&out, 64));
+#define R(K, N) run<K, 8>(N, out); run<K, 2>(N, out)
+    R(0, "v_fma_f32 v,v,v"); R(1, "v_fma_f32 s,v,v"); R(2, "v_fmaak_f32 v,v,literal"); R(14, "v_fmamk_f32 v,literal,v");
+    R(3, "v_fma_f32 v,v,1.0 (inline)"); R(10, "v_fma_f32 v,s,s");
+    R(9, "v_fmac_f32_e32 v,v"); R(4, "v_mul_f32_e32 v,v"); R(5, "v_mul_f32_e32 s,v"); R(6, "v_mul_f32_e32 literal,v");
+    R(7, "v_add_f32_e32 v,v"); R(8, "v_add_f32_e32 s,v"); R(13, "v_mul v,v + v_add v,v");
+    R(11, "v_max_f32_e32 v,v"); R(12, "v_cvt_f32_u32_e32"); R(15, "v_cndmask_b32_e32"); R(16, "v_lshl_add_u32 (VOP3)"); R(17, "v_rndne_f32_e32");
+    return 0;
+}
