@@ -171,9 +171,12 @@ struct rd_tickets {
 
 template <int FMT, bool HIST, int MATH>
 static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t unit0,
-                              uint32_t unit1, uint32_t blocks, const rd_ku &u, uint32_t *slab32,
+                              uint32_t unit1, uint32_t blocks, const rd_ku &u_in, uint32_t *slab32,
                               unsigned long long *slab64, uint32_t *tq, hipStream_t s)
 {
+    static const bool no_elide = rd_env_u32("RD_NO_ELIDE", 0) != 0;    // A/B switch: evaluate every step (rd_uniforms.h RD_EL_*)
+    rd_ku u = u_in;
+    if (no_elide) u.elide = 0u;
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
     const uint32_t tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;   // rd_kernels.h: split()
     const uint32_t nwaves = blocks * RD_WAVES;

@@ -146,6 +146,110 @@ __device__ __forceinline__ rd_rgb rd_colour_m(const rd_ku &u, float r, float g, 
     return MATH == RD_MATH_CONTRACTED ? rd_colour_c(u, r, g, b) : rd_colour(u, r, g, b);
 }
 
+// The export kernel's form of the two functions above: N colour triples advanced together, stage by stage, each triple
+// seeing exactly the operation sequence of rd_colour / rd_colour_c, and every stage that u.elide (rd_uniforms.h) marks as
+// an exact identity for this frame's uniforms skipped behind ONE wave-uniform branch for all N.  With all sliders away
+// from their defaults nothing is skipped; a typical edit (identity matrix -- the reference never passes another one --
+// and a few untouched sliders) sheds a quarter of the linear part.  Results are written back into r, g, b.
+template <int N, int MATH>
+__device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
+{
+    constexpr bool C = MATH == RD_MATH_CONTRACTED;
+    const uint32_t el = u.elide;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r[i] = r[i] * u.wb_r; g[i] = g[i] * u.wb_g; b[i] = b[i] * u.wb_b; }          // :195
+    if (!(el & RD_EL_K)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = r[i] * u.kr; b[i] = b[i] * u.kb; g[i] = g[i] * u.kg; }            // :200-205
+    }
+    if (!(el & RD_EL_MAT)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {                                                                          // :209-214
+            float x, y, z;
+            if (C) {
+                x = __builtin_fmaf(u.m[6], b[i], __builtin_fmaf(u.m[3], g[i], u.m[0] * r[i]));
+                y = __builtin_fmaf(u.m[7], b[i], __builtin_fmaf(u.m[4], g[i], u.m[1] * r[i]));
+                z = __builtin_fmaf(u.m[8], b[i], __builtin_fmaf(u.m[5], g[i], u.m[2] * r[i]));
+            } else {
+                x = ((u.m[0] * r[i]) + (u.m[3] * g[i])) + (u.m[6] * b[i]);
+                y = ((u.m[1] * r[i]) + (u.m[4] * g[i])) + (u.m[7] * b[i]);
+                z = ((u.m[2] * r[i]) + (u.m[5] * g[i])) + (u.m[8] * b[i]);
+            }
+            r[i] = x; g[i] = y; b[i] = z;
+        }
+    }
+    if (!(el & RD_EL_EM)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = r[i] * u.em; g[i] = g[i] * u.em; b[i] = b[i] * u.em; }            // :217-218
+    }
+    if ((el & (RD_EL_HL | RD_EL_SH)) != (RD_EL_HL | RD_EL_SH)) {
+        float L[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) L[i] = C ? rd_dot709_c(r[i], g[i], b[i]) : rd_dot709(r[i], g[i], b[i]);    // :222
+        if (!(el & RD_EL_HL)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {                                                                      // :226
+                const float hl = C ? __builtin_fmaf(L[i], u.highlights, 1.0f) : 1.0f + (L[i] * u.highlights);
+                r[i] = r[i] * hl; g[i] = g[i] * hl; b[i] = b[i] * hl;
+            }
+        }
+        if (!(el & RD_EL_SH)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {                                                                      // :230
+                const float sh = C ? __builtin_fmaf(1.0f - L[i], u.shadows, 1.0f) : 1.0f + ((1.0f - L[i]) * u.shadows);
+                r[i] = r[i] * sh; g[i] = g[i] * sh; b[i] = b[i] * sh;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {                                                                              // :233-239
+        if (C) {
+            r[i] = __builtin_fmaf(r[i] - 0.5f, u.cf, 0.5f);
+            g[i] = __builtin_fmaf(g[i] - 0.5f, u.cf, 0.5f);
+            b[i] = __builtin_fmaf(b[i] - 0.5f, u.cf, 0.5f);
+            r[i] = (r[i] - u.blacks) * u.rden;
+            g[i] = (g[i] - u.blacks) * u.rden;
+            b[i] = (b[i] - u.blacks) * u.rden;
+        } else {
+            r[i] = (r[i] - 0.5f) * u.cf + 0.5f;
+            g[i] = (g[i] - 0.5f) * u.cf + 0.5f;
+            b[i] = (b[i] - 0.5f) * u.cf + 0.5f;
+            r[i] = rd_div_den(u, r[i] - u.blacks);
+            g[i] = rd_div_den(u, g[i] - u.blacks);
+            b[i] = rd_div_den(u, b[i] - u.blacks);
+        }
+    }
+    if (!(el & RD_EL_SAT)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {                                                                          // :243-247
+            const float Y = C ? rd_dot709_c(r[i], g[i], b[i]) : rd_dot709(r[i], g[i], b[i]);
+            const float ys = Y * u.oms;
+            if (C) { r[i] = __builtin_fmaf(r[i], u.s, ys); g[i] = __builtin_fmaf(g[i], u.s, ys); b[i] = __builtin_fmaf(b[i], u.s, ys); }
+            else { r[i] = ys + r[i] * u.s; g[i] = ys + g[i] * u.s; b[i] = ys + b[i] * u.s; }
+        }
+    }
+    if (!(el & RD_EL_VIB)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {                                                                          // :251-257
+            const float sat = __builtin_fmaxf(r[i], __builtin_fmaxf(g[i], b[i])) - __builtin_fminf(r[i], __builtin_fminf(g[i], b[i]));
+            if (C) {
+                const float a2 = __builtin_fmaf(u.vibrance, 1.0f - sat, 1.0f);
+                const float Y2 = rd_dot709_c(r[i], g[i], b[i]);
+                const float yv = Y2 * (1.0f - a2);
+                r[i] = __builtin_fmaf(r[i], a2, yv); g[i] = __builtin_fmaf(g[i], a2, yv); b[i] = __builtin_fmaf(b[i], a2, yv);
+            } else {
+                const float va = u.vibrance * (1.0f - sat);
+                const float Y2 = rd_dot709(r[i], g[i], b[i]);
+                const float a2 = 1.0f + va;
+                const float yv = Y2 * (1.0f - a2);
+                r[i] = yv + r[i] * a2; g[i] = yv + g[i] * a2; b[i] = yv + b[i] * a2;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r[i] = rd_gamma_clamp(r[i]); g[i] = rd_gamma_clamp(g[i]); b[i] = rd_gamma_clamp(b[i]); }   // :261-264
+}
+
 // f32(raw)/4096 (shaders.rs:106-110, :167-168) with the optional integer black level.
 __device__ __forceinline__ float rd_norm(uint32_t raw, uint32_t bl)
 {
@@ -293,8 +397,18 @@ template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST =
 __global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                  uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k,
-                 uint32_t tq_tmax, uint32_t *tq, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
+                 uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
 {
+    // Register budget: two workgroups per CU need <= 80 SGPRs AND <= 64 VGPRs per wave (RD_NUM_SGPR above).  The uniforms of
+    // the front of the stack (white balance, temperature/tint, matrix: 15 values) are therefore parked in VGPRs -- the asm
+    // keeps the compiler from folding them back into scalar operands -- which leaves the kernel at ~62 SGPRs / ~60 VGPRs
+    // with no spill.  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
+    // that is not what limits this kernel: DESIGN.md section 6.)
+    rd_ku u = u_arg;
+#define RD_PARK(f) asm volatile("v_mov_b32 %0, %1" : "=v"(u.f) : "s"(u_arg.f))
+    RD_PARK(wb_r); RD_PARK(wb_g); RD_PARK(wb_b); RD_PARK(kr); RD_PARK(kg); RD_PARK(kb);
+    RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
+#undef RD_PARK
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[(FMT == RD_FMT_RGBA_F32 || BURST) ? RD_BLOCK * 3 : 1];
@@ -364,9 +478,15 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
         const bool valid = FULL || (tq * 64u + lane) < qpr;
         const float A = rd_norm(top & 0xffffu, u.black_level), B = rd_norm(top >> 16, u.black_level);
         const float C = rd_norm(bot & 0xffffu, u.black_level), D = rd_norm(bot >> 16, u.black_level);
+#ifdef RD_COLOUR_HOOK_HEADER
         const rd_rgb c1 = RD_COLOUR(u, C, A, B);
         const rd_rgb c2 = RD_COLOUR(u, C, D, A);
         const rd_rgb c3 = RD_COLOUR(u, C, D, B);
+#else
+        float tr[3] = { C, C, C }, tg[3] = { A, D, D }, tb[3] = { B, A, B };       // row a: (C,A,B); row b: (C,D,A), (C,D,B)
+        rd_colour_n<3, MATH>(u, tr, tg, tb);
+        const rd_rgb c1 = { tr[0], tg[0], tb[0] }, c2 = { tr[1], tg[1], tb[1] }, c3 = { tr[2], tg[2], tb[2] };
+#endif
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
         if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);

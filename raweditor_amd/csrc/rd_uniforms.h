@@ -24,6 +24,23 @@ struct rd_ku {
     float vibrance;              // :254
     float zoom, pan_x, pan_y;    // :46-51
     uint32_t black_level;        // extension (0 = reference)
+    uint32_t elide;              // RD_EL_*: steps that are exact identities for THESE uniforms (export kernel)
+};
+
+// Steps of the colour stack the export kernel may skip because, for the uniforms of this frame, they return their input
+// bit for bit: x*1 is x for every x; with a zero slider the factor 1 + (finite * 0) is exactly 1; an identity matrix gives
+// (1*r + 0*g) + 0*b = r.  The "finite" is the catch (0 * inf is NaN), so everything except the x*1 cases is only flagged
+// when rd_make_ku can bound every intermediate of the stack far below FLT_MAX from the uniforms and the input range
+// [0, 16).  The sign of a zero may differ from the literal evaluation; it cannot reach the surface (the contrast step
+// maps both zeros to -0.5, the gamma step maps both to +0).  The oracle never skips anything.
+enum {
+    RD_EL_K = 1u,        // temperature = tint = 0: the three factors are 1          (shaders.rs:200-205)
+    RD_EL_MAT = 2u,      // identity colour matrix -- the only one the reference ever passes (color.rs:43-47)
+    RD_EL_EM = 4u,       // exposure = 0: pow(2, 0) = 1                               (:217-218)
+    RD_EL_HL = 8u,       // highlights = 0                                           (:226)
+    RD_EL_SH = 16u,      // shadows = 0                                              (:230)
+    RD_EL_SAT = 32u,     // saturation = 0: mix(Y, c, 1)                             (:245-247)
+    RD_EL_VIB = 64u,     // vibrance = 0: mix(Y2, c, 1)                              (:251-257)
 };
 
 static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const float cm[9],
@@ -59,5 +76,36 @@ static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const
     u.vibrance = p.vibrance;
     u.zoom = zoom; u.pan_x = pan_x; u.pan_y = pan_y;
     u.black_level = black_level;
+    u.elide = 0u;
+    if (u.kr == 1.0f && u.kg == 1.0f && u.kb == 1.0f) u.elide |= RD_EL_K;
+    if (u.em == 1.0f) u.elide |= RD_EL_EM;
+    {   // magnitude bounds through the stack, in double; any NaN makes a comparison false and leaves the flags clear
+        const double in = 16.0;                                    // 65535 / 4096 < 16
+        const double ar = in * __builtin_fabs((double)u.wb_r) * __builtin_fabs((double)u.kr);
+        const double ag = in * __builtin_fabs((double)u.wb_g) * __builtin_fabs((double)u.kg);
+        const double ab = in * __builtin_fabs((double)u.wb_b) * __builtin_fabs((double)u.kb);
+        double a = 0.0;
+        for (int row = 0; row < 3; ++row) {
+            const double v = __builtin_fabs((double)u.m[row]) * ar + __builtin_fabs((double)u.m[3 + row]) * ag +
+                             __builtin_fabs((double)u.m[6 + row]) * ab;
+            a = v > a ? v : a;
+        }
+        a *= __builtin_fabs((double)u.em);                         // after :217-218; |L| <= 1.0001 a
+        const double hl = 1.0 + 1.0001 * a * __builtin_fabs((double)u.highlights);
+        const double sh = 1.0 + (1.0 + 1.0001 * a) * __builtin_fabs((double)u.shadows);
+        const double a5 = a * hl * sh;                             // after :230
+        const double a6 = (a5 + 0.5) * __builtin_fabs((double)u.cf) + 0.5;
+        const double a7 = (a6 + __builtin_fabs((double)u.blacks)) * __builtin_fabs((double)u.rden) * 1.0001;
+        const double a8 = a7 * 1.0001 * __builtin_fabs((double)u.oms) + a7 * __builtin_fabs((double)u.s);
+        const double lim = 1.0e30;
+        const bool front = ar < lim && ag < lim && ab < lim && a < lim;
+        const bool identity = u.m[0] == 1.0f && u.m[4] == 1.0f && u.m[8] == 1.0f && u.m[1] == 0.0f && u.m[2] == 0.0f &&
+                              u.m[3] == 0.0f && u.m[5] == 0.0f && u.m[6] == 0.0f && u.m[7] == 0.0f;
+        if (front && identity) u.elide |= RD_EL_MAT;
+        if (front && u.highlights == 0.0f) u.elide |= RD_EL_HL;
+        if (front && u.shadows == 0.0f) u.elide |= RD_EL_SH;
+        if (front && a5 < lim && a6 < lim && a7 < lim && u.fast_div && u.s == 1.0f && u.oms == 0.0f) u.elide |= RD_EL_SAT;
+        if (front && a5 < lim && a6 < lim && a7 < lim && a8 < lim && u.fast_div && u.vibrance == 0.0f) u.elide |= RD_EL_VIB;
+    }
     return u;
 }

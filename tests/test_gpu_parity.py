@@ -209,6 +209,41 @@ def test_out_of_range_and_degenerate_params(gpu_lib, refc):
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (params, wb)
 
 
+def test_identity_step_elision_is_exact(gpu_lib, refc):
+    """The export kernel skips steps of the stack that are exact identities for a frame's uniforms (rd_uniforms.h RD_EL_*);
+    the oracle never skips anything.  Untouched sliders in every combination with the identity matrix, zeros in the CFA
+    (signed-zero paths), and the cases where the skip must NOT be taken because an intermediate can overflow
+    (0 * inf is NaN in the literal evaluation): all bit-identical, on the export kernel and on the general one."""
+    ra = gpu_lib
+    rng = np.random.default_rng(23)
+    cfa = random_cfa(rng, 36, 256, 65536)
+    cfa[::5, ::3] = 0
+    full = {"exposure": 0.7, "contrast": 5.0, "highlights": -0.4, "shadows": 0.3, "whites": 1.05, "blacks": 0.02,
+            "vibrance": 0.4, "saturation": 25.0, "temperature": 0.25, "tint": -0.15}
+    stacks = [({}, WB_DAYLIGHT, CM_IDENTITY), ({}, (1, 1, 1, 1), CM_IDENTITY), (full, WB_DAYLIGHT, CM_IDENTITY)]
+    for drop in (("highlights",), ("shadows",), ("vibrance",), ("saturation",), ("temperature", "tint"), ("exposure",),
+                 ("highlights", "shadows"), ("vibrance", "saturation"), ("exposure", "temperature", "tint", "vibrance")):
+        p = {k: v for k, v in full.items() if k not in drop}
+        stacks.append((p, WB_DAYLIGHT, CM_IDENTITY))
+        stacks.append((p, WB_DAYLIGHT, CM_TEST))
+    # overflow guards: the flags must stay clear, inf * 0 -> NaN -> 0 exactly as in the literal evaluation
+    stacks += [({"exposure": 126.0}, WB_DAYLIGHT, CM_IDENTITY), ({"exposure": 200.0}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"exposure": 110.0, "contrast": 40.0}, WB_DAYLIGHT, CM_IDENTITY),
+               ({}, (1e38, 1e38, 1e38, 1.0), CM_IDENTITY), ({"whites": 0.0, "blacks": 0.0001}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"whites": 0.2, "blacks": 0.2, "exposure": 90.0}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"exposure": 100.0}, WB_DAYLIGHT, (1e30, 0, 0, 0, 1e30, 0, 0, 0, 1e30))]
+    for math in (0, 1):
+        for params, wb, cm in stacks:
+            exp = oracle(refc, cfa, params, wb, cm, math=math)
+            pipe = make_pipe(ra, cfa, params, wb, cm, math=math)
+            got, hist = pipe.render(None, None, ra.FMT_RGBA_F32, with_histogram=True)
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (math, params, wb, cm)
+            assert np.array_equal(hist, refc.histogram(refc.pack_u8(exp)))
+            with force_map():
+                got_map = pipe.render()
+            assert np.array_equal(got_map.view(np.uint32), exp.view(np.uint32)), ("map", math, params)
+
+
 def test_black_level_extension(gpu_lib, refc):
     ra = gpu_lib
     cfa = random_cfa(np.random.default_rng(9), 18, 26)
