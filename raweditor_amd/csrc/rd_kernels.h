@@ -538,10 +538,10 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             for (uint32_t half = 0; half < 2u; ++half) {
                 const uint32_t p = half * 64u + lane;                  // pixel within the tile
                 const uint32_t px = tq * 128u + p;                     // column
-                rd_f4 va = st[(p >> 1) * 3u];                          // row a: c1 of quad p/2
-                rd_f4 vb = st[(p >> 1) * 3u + 1u + (p & 1u)];          // row b: c2 (even col) / c3 (odd col)
-                if (!has_a) va = vb;
-                if (!has_b) vb = va;
+                const uint32_t ja = (p >> 1) * 3u;                     // row a: c1 of quad p/2
+                const uint32_t jb = ja + 1u + (p & 1u);                // row b: c2 (even col) / c3 (odd col)
+                const rd_f4 va = st[has_a ? ja : jb];                  // a missing row re-stores the other one: the select is
+                const rd_f4 vb = st[has_b ? jb : ja];                  // made on the LDS index (2 per half), not on 8 floats
                 if (FULL || px < W) {
 #ifdef RD_ST_PLAIN
                     o[row_a_px + px] = va;

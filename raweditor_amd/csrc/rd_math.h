@@ -40,9 +40,16 @@ RD_HD float rd_log2f(float x)
 }
 
 // 2^z for z in [-126, 128): n = rint(z) (ties to even), f = z-n, Q(f) of degree 6, exponent add.
+// rint is taken with the add-magic idiom: for |z| < 2^22, t = RN(z + 1.5*2^23) carries the integer nearest to z (ties to
+// even, the FPU's own rounding) in its low mantissa bits, t - 1.5*2^23 is that integer exactly, and because the low nine
+// bits of the magic constant's encoding are zero, bits(t) << 23 == (uint32)n << 23.  Same n, same f, same result as
+// rintf + float->int conversion, in four instructions, three of them full-rate adds (v_rndne_f32 and v_cvt_i32_f32 are
+// half rate on gfx950).  No fast-math anywhere in this project, so (z + c) - c is not folded.
 RD_HD float rd_exp2f_core(float z)
 {
-    float n = __builtin_rintf(z);
+    const float magic = 12582912.0f;           // 1.5 * 2^23 = 0x4b400000
+    float t = z + magic;
+    float n = t - magic;
     float f = z - n;
     float p = 0x1.43e9d6p-13f;
     p = __builtin_fmaf(p, f, 0x1.5f4e2ep-10f);
@@ -51,7 +58,7 @@ RD_HD float rd_exp2f_core(float z)
     p = __builtin_fmaf(p, f, 0x1.ebfbep-3f);
     p = __builtin_fmaf(p, f, 0x1.62e43p-1f);
     p = __builtin_fmaf(p, f, 1.0f);
-    return rd_u2f(rd_f2u(p) + ((uint32_t)(int32_t)n << 23));
+    return rd_u2f(rd_f2u(p) + (rd_f2u(t) << 23));
 }
 
 // Full-domain 2^z: NaN -> NaN, z >= 128 -> +inf, z < -126 -> 0 (sub-FLT_MIN results flush).
@@ -70,7 +77,7 @@ RD_HD float rd_exp2f(float z)
 RD_HD float rd_gamma_clamp(float x)
 {
     float z = RD_INV_GAMMA * rd_log2f(x);
-    float v = rd_exp2f_core(z);
-    v = v < 1.0f ? v : 1.0f;
-    return (x >= RD_FLT_MIN) ? v : 0.0f;
+    uint32_t v = rd_f2u(rd_exp2f_core(z));
+    v = v < 0x3f800000u ? v : 0x3f800000u;     // min(v, 1.0f) on the encodings: v is a positive finite float whenever it is used
+    return (x >= RD_FLT_MIN) ? rd_u2f(v) : 0.0f;
 }

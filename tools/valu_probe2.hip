@@ -13,6 +13,7 @@ __global__ void __launch_bounds__(1024) k(float *out, float a, float b, int iter
 {
     float av = a, bv = b;
     asm volatile("" : "+v"(av), "+v"(bv));
+    unsigned long long mask64 = 0x5555555555555555ull; asm volatile("" : "+s"(mask64));
     float x[ILP];
 #pragma unroll
     for (int i = 0; i < ILP; ++i) x[i] = (float)(threadIdx.x + i) * 1e-3f;
@@ -40,6 +41,15 @@ __global__ void __launch_bounds__(1024) k(float *out, float a, float b, int iter
                 if (KIND == 15) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v) : "v"(bv));
                 if (KIND == 16) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(v) : "v"(bv));
                 if (KIND == 17) asm volatile("v_rndne_f32_e32 %0, %0" : "+v"(v));
+                if (KIND == 18) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v) : "v"(bv), "s"(mask64));
+                if (KIND == 19) asm volatile("v_cmp_le_f32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, 0, %0, vcc" : "+v"(v) : "v"(bv) : "vcc");
+                if (KIND == 20) asm volatile("v_cmp_le_f32_e32 vcc, %1, %0" : : "v"(v), "v"(bv) : "vcc");
+                if (KIND == 21) asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 22) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 23) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 24) asm volatile("v_and_b32_e32 %0, 0x7fffff, %0" : "+v"(v));
+                if (KIND == 25) asm volatile("v_add_u32_e32 %0, 0x3f3504f3, %0" : "+v"(v));
+                if (KIND == 26) asm volatile("v_ashrrev_i32_e32 %0, 23, %0" : "+v"(v));
             }
     }
     float s = 0;
@@ -72,6 +82,8 @@ int main()
     R(3, "v_fma_f32 v,v,1.0 (inline)"); R(10, "v_fma_f32 v,s,s");
     R(9, "v_fmac_f32_e32 v,v"); R(4, "v_mul_f32_e32 v,v"); R(5, "v_mul_f32_e32 s,v"); R(6, "v_mul_f32_e32 literal,v");
     R(7, "v_add_f32_e32 v,v"); R(8, "v_add_f32_e32 s,v"); R(13, "v_mul v,v + v_add v,v");
-    R(11, "v_max_f32_e32 v,v"); R(12, "v_cvt_f32_u32_e32"); R(15, "v_cndmask_b32_e32"); R(16, "v_lshl_add_u32 (VOP3)"); R(17, "v_rndne_f32_e32");
+    R(11, "v_max_f32_e32 v,v"); R(12, "v_cvt_f32_u32_e32"); R(15, "v_cndmask_b32_e32 (vcc never written)"); R(16, "v_lshl_add_u32 (VOP3)"); R(17, "v_rndne_f32_e32");
+    R(18, "v_cndmask_b32_e64 v,v,s[pair]"); R(19, "v_cmp_le + v_cndmask (2 instr, per pair)"); R(20, "v_cmp_le_f32 vcc"); R(21, "v_min_u32_e32");
+    R(22, "v_min3_f32"); R(23, "v_div_fixup_f32"); R(24, "v_and_b32 literal"); R(25, "v_add_u32 literal"); R(26, "v_ashrrev_i32");
     return 0;
 }
