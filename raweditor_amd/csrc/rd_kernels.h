@@ -202,22 +202,50 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) {                                                                              // :233-239
+    for (int i = 0; i < N; ++i) {                                                                              // :233-234
         if (C) {
             r[i] = __builtin_fmaf(r[i] - 0.5f, u.cf, 0.5f);
             g[i] = __builtin_fmaf(g[i] - 0.5f, u.cf, 0.5f);
             b[i] = __builtin_fmaf(b[i] - 0.5f, u.cf, 0.5f);
-            r[i] = (r[i] - u.blacks) * u.rden;
-            g[i] = (g[i] - u.blacks) * u.rden;
-            b[i] = (b[i] - u.blacks) * u.rden;
         } else {
             r[i] = (r[i] - 0.5f) * u.cf + 0.5f;
             g[i] = (g[i] - 0.5f) * u.cf + 0.5f;
             b[i] = (b[i] - 0.5f) * u.cf + 0.5f;
-            r[i] = rd_div_den(u, r[i] - u.blacks);
-            g[i] = rd_div_den(u, g[i] - u.blacks);
-            b[i] = rd_div_den(u, b[i] - u.blacks);
         }
+    }
+    if (!(el & RD_EL_BLK)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = r[i] - u.blacks; g[i] = g[i] - u.blacks; b[i] = b[i] - u.blacks; }   // :239
+    }
+    if (C) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = r[i] * u.rden; g[i] = g[i] * u.rden; b[i] = b[i] * u.rden; }
+    } else if (u.fast_div) {                                     // rd_div_den for all 3N values behind ONE pair of branches
+        float q[3 * N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { q[3 * i] = r[i]; q[3 * i + 1] = g[i]; q[3 * i + 2] = b[i]; }
+#pragma unroll
+        for (int k = 0; k < 3 * N; ++k) {
+            const float a = q[k];
+            float t = a * u.rden;
+            float e = __builtin_fmaf(-u.den, t, a);
+            t = __builtin_fmaf(e, u.rden, t);
+            e = __builtin_fmaf(-u.den, t, a);
+            q[k] = __builtin_fmaf(e, u.rden, t);
+        }
+        if (!(el & RD_EL_FIX)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                q[3 * i] = __builtin_amdgcn_div_fixupf(q[3 * i], u.den, r[i]);
+                q[3 * i + 1] = __builtin_amdgcn_div_fixupf(q[3 * i + 1], u.den, g[i]);
+                q[3 * i + 2] = __builtin_amdgcn_div_fixupf(q[3 * i + 2], u.den, b[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = q[3 * i]; g[i] = q[3 * i + 1]; b[i] = q[3 * i + 2]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = r[i] / u.den; g[i] = g[i] / u.den; b[i] = b[i] / u.den; }
     }
     if (!(el & RD_EL_SAT)) {
 #pragma unroll
@@ -400,7 +428,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
                  uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
 {
     // Register budget: two workgroups per CU need <= 80 SGPRs AND <= 64 VGPRs per wave (RD_NUM_SGPR above).  The uniforms of
-    // the front of the stack (white balance, temperature/tint, matrix: 15 values) are therefore parked in VGPRs -- the asm
+    // the front of the stack (white balance, temperature/tint, matrix) and of the levels divide (17 values) are therefore parked in VGPRs -- the asm
     // keeps the compiler from folding them back into scalar operands -- which leaves the kernel at ~62 SGPRs / ~60 VGPRs
     // with no spill.  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
     // that is not what limits this kernel: DESIGN.md section 6.)
@@ -408,6 +436,10 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
 #define RD_PARK(f) asm volatile("v_mov_b32 %0, %1" : "=v"(u.f) : "s"(u_arg.f))
     RD_PARK(wb_r); RD_PARK(wb_g); RD_PARK(wb_b); RD_PARK(kr); RD_PARK(kg); RD_PARK(kb);
     RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
+    RD_PARK(den); RD_PARK(rden);                                 // 36 uses per tile in the divide's FMA chains
+    if constexpr (FMT != RD_FMT_RGBA_F32) {                      // the narrower surfaces carry fewer live VGPRs: park six more
+        RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
+    }
 #undef RD_PARK
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];

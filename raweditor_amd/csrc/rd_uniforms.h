@@ -41,6 +41,9 @@ enum {
     RD_EL_SH = 16u,      // shadows = 0                                              (:230)
     RD_EL_SAT = 32u,     // saturation = 0: mix(Y, c, 1)                             (:245-247)
     RD_EL_VIB = 64u,     // vibrance = 0: mix(Y2, c, 1)                              (:251-257)
+    RD_EL_FIX = 128u,    // levels divide: numerator finite and far from the exponent limits, so v_div_fixup_f32 only
+                         // ever passes the quotient through (its other cases: NaN, inf, zero denominators, exponent overflow)
+    RD_EL_BLK = 256u,    // blacks = 0: c - 0 = c                                    (:239)
 };
 
 static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const float cm[9],
@@ -106,6 +109,9 @@ static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const
         if (front && u.shadows == 0.0f) u.elide |= RD_EL_SH;
         if (front && a5 < lim && a6 < lim && a7 < lim && u.fast_div && u.s == 1.0f && u.oms == 0.0f) u.elide |= RD_EL_SAT;
         if (front && a5 < lim && a6 < lim && a7 < lim && a8 < lim && u.fast_div && u.vibrance == 0.0f) u.elide |= RD_EL_VIB;
+        const double ad = __builtin_fabs((double)u.den);
+        if (front && a5 < lim && a6 < lim && a7 < lim && u.fast_div && ad > 1.0e-30 && ad < lim) u.elide |= RD_EL_FIX;
+        if (u.blacks == 0.0f) u.elide |= RD_EL_BLK;
     }
     return u;
 }

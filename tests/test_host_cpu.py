@@ -154,3 +154,20 @@ def test_product_never_reaches_into_the_oracle():
                     if any(p.search(line) for p in pats):
                         bad.append((f, line.strip()))
     assert not bad, bad
+
+
+def test_export_kernel_register_budget():
+    """Two 1024-thread workgroups share a CU only while a wave needs <= 64 VGPRs, <= 80 SGPRs and no scratch (hipcc
+    reports 'occupancy 8' even when the SGPR budget is blown; measured: the second workgroup then waits for the first).
+    The build records hipcc's own resource remarks; every instance of the export kernel must stay inside."""
+    from raweditor_amd import build
+    res = build.load_resources()
+    quads = {k: v for k, v in res.items() if "rd_develop_quads" in k}
+    assert len(quads) >= 32, "resource remarks missing: was the library built without -Rpass-analysis?"
+    for name, r in quads.items():
+        assert r["vgprs"] <= 64 and r["sgprs"] <= 80 and r["scratch"] == 0 and r["occupancy"] >= 8, (name, r)
+        assert r["lds"] <= 80 * 1024, (name, r)                 # two workgroups in the CU's 160 KiB
+    build.check_resources(res)
+    import pytest
+    with pytest.raises(RuntimeError):
+        build.check_resources({"rd_develop_quads<x>": {"vgprs": 72, "sgprs": 78, "scratch": 0}})
