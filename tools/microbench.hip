@@ -294,7 +294,7 @@ struct Variant { std::string name; std::function<void(int)> run; std::vector<flo
 int main(int argc, char **argv)
 {
     const uint32_t W = 6016, H = 4016;
-    const int NIN = 8, NOUT = 4, ROUNDS = argc > 1 ? atoi(argv[1]) : 6, REP = 8;
+    const int NIN = getenv("MB_NIN") ? atoi(getenv("MB_NIN")) : 8, NOUT = 4, ROUNDS = argc > 1 ? atoi(argv[1]) : 6, REP = 8;
     const size_t in_bytes = (size_t)W * H * 2, out_bytes = (size_t)W * H * 16;
     std::vector<uint16_t *> din(NIN); std::vector<float *> dout(NOUT);
     std::vector<uint16_t> host((size_t)W * H);
