@@ -141,7 +141,9 @@ int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format, v
 /* Device-resident variant: `dst_dev` (and nullable `hist_dev`, 768 x u32) are device pointers on
  * the pipeline's device; work is enqueued on `stream` (a hipStream_t, NULL = default stream) and
  * NOT synchronised.  The fused histogram uses scratch owned by the pipeline: renders WITH a histogram on one
- * pipeline must be enqueued on one stream at a time (renders without one may overlap freely). */
+ * pipeline must be enqueued on one stream at a time (renders without one may overlap freely).  The first
+ * full-resolution render on a stream allocates that stream's 32 KiB of tile-scheduler state (synchronous; do it before
+ * capturing the stream into a graph). */
 int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format,
                      void *dst_dev, uint32_t *hist_dev, void *stream);
 
