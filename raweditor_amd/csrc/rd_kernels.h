@@ -38,117 +38,31 @@ typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
 struct rd_rgb { float r, g, b; };
 
 // ---------------------------------------------------------------------------------------------
-// shaders.rs:192-266 on one demosaiced triple.  Literal operation order of the WGSL text; this TU
-// is compiled with -ffp-contract=off so nothing here fuses.  `/` is the IEEE-correct divide.
+// The colour stack (shaders.rs:192-266): rd_colour_n below; rd_dot709 is its Rec.709 luma (:222, :243, :256).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rd_dot709(float r, float g, float b)
 {
     return ((r * 0.2126f) + (g * 0.7152f)) + (b * 0.0722f);
 }
 
-// a / u.den, correctly rounded (shaders.rs:239).  The denominator is uniform, so its correctly
-// rounded reciprocal u.rden comes from the host; two residual corrections (Markstein: y = RN(1/d),
-// q faithful  =>  RN(q + (a - d*q)*y) = RN(a/d)) give the IEEE quotient in 5 FMAs instead of the
-// ~14-instruction generic v_div_scale/v_rcp/v_div_fmas expansion; v_div_fixup_f32 restores the
-// IEEE special cases (a = 0/inf/NaN, d = 0).  u.fast_div is cleared by the host when d or 1/d is
-// not a normal finite number; the generic divide runs then.  tools/div_check.c: 10^9 samples equal.
-__device__ __forceinline__ float rd_div_den(const rd_ku &u, float a)
-{
-    if (!u.fast_div) return a / u.den;
-    float q = a * u.rden;
-    float e = __builtin_fmaf(-u.den, q, a);
-    q = __builtin_fmaf(e, u.rden, q);
-    e = __builtin_fmaf(-u.den, q, a);
-    q = __builtin_fmaf(e, u.rden, q);
-    return __builtin_amdgcn_div_fixupf(q, u.den, a);
-}
+// a / u.den, correctly rounded (shaders.rs:239).  The denominator is uniform, so its correctly rounded reciprocal u.rden
+// comes from the host; two residual corrections (Markstein: y = RN(1/d), q faithful  =>  RN(q + (a - d*q)*y) = RN(a/d))
+// give the IEEE quotient in 5 FMAs instead of the ~14-instruction generic v_div_scale/v_rcp/v_div_fmas expansion;
+// v_div_fixup_f32 restores the IEEE special cases (a = 0/inf/NaN, d = 0).  u.fast_div is cleared by the host when d or
+// 1/d is not a normal finite number; the generic divide runs then.  tools/div_check.c: 10^9 samples equal.  (The
+// sequence lives in rd_colour_n below, evaluated for all values of a tile behind one branch.)
 
-__device__ __forceinline__ rd_rgb rd_colour(const rd_ku &u, float r, float g, float b)
-{
-    r = r * u.wb_r; g = g * u.wb_g; b = b * u.wb_b;                    // :195
-    r = r * u.kr; b = b * u.kb; g = g * u.kg;                          // :200-205
-    float x = ((u.m[0] * r) + (u.m[3] * g)) + (u.m[6] * b);            // :209-214 (columns)
-    float y = ((u.m[1] * r) + (u.m[4] * g)) + (u.m[7] * b);
-    float z = ((u.m[2] * r) + (u.m[5] * g)) + (u.m[8] * b);
-    r = x * u.em; g = y * u.em; b = z * u.em;                          // :217-218
-    float L = rd_dot709(r, g, b);                                      // :222
-    float hl = 1.0f + (L * u.highlights);                              // :226
-    r = r * hl; g = g * hl; b = b * hl;
-    float sh = 1.0f + ((1.0f - L) * u.shadows);                        // :230
-    r = r * sh; g = g * sh; b = b * sh;
-    r = (r - 0.5f) * u.cf + 0.5f;                                      // :233-234
-    g = (g - 0.5f) * u.cf + 0.5f;
-    b = (b - 0.5f) * u.cf + 0.5f;
-    r = rd_div_den(u, r - u.blacks);                                   // :239
-    g = rd_div_den(u, g - u.blacks);
-    b = rd_div_den(u, b - u.blacks);
-    float Y = rd_dot709(r, g, b);                                      // :243
-    float ys = Y * u.oms;                                              // mix(Y, c, s) :247
-    r = ys + r * u.s; g = ys + g * u.s; b = ys + b * u.s;
-    float sat = __builtin_fmaxf(r, __builtin_fmaxf(g, b)) - __builtin_fminf(r, __builtin_fminf(g, b)); // :251
-    float va = u.vibrance * (1.0f - sat);                              // :254
-    float Y2 = rd_dot709(r, g, b);                                     // :256
-    float a2 = 1.0f + va;
-    float yv = Y2 * (1.0f - a2);                                       // mix(Y2, c, 1+va) :257
-    r = yv + r * a2; g = yv + g * a2; b = yv + b * a2;
-    rd_rgb o;                                                          // :261-264
-    o.r = rd_gamma_clamp(r);
-    o.g = rd_gamma_clamp(g);
-    o.b = rd_gamma_clamp(b);
-    return o;
-}
-
-// RD_MATH_CONTRACTED: the same shader text with every a*b+c contracted to one fma and the levels
-// division done as x*RN(1/d) -- the lowering an AMD shader compiler applies to the reference's WGSL
-// (oracle: colour_stack_contracted).  ~62 VALU + 3 pow instead of ~105 + 3 pow.
-__device__ __forceinline__ float rd_dot709_c(float r, float g, float b)
+__device__ __forceinline__ float rd_dot709_c(float r, float g, float b)      // the same dot product, contracted
 {
     return __builtin_fmaf(b, 0.0722f, __builtin_fmaf(g, 0.7152f, r * 0.2126f));
 }
 
-__device__ __forceinline__ rd_rgb rd_colour_c(const rd_ku &u, float r, float g, float b)
-{
-    r = r * u.wb_r; g = g * u.wb_g; b = b * u.wb_b;                    // :195
-    r = r * u.kr; b = b * u.kb; g = g * u.kg;                          // :200-205
-    float x = __builtin_fmaf(u.m[6], b, __builtin_fmaf(u.m[3], g, u.m[0] * r));   // :209-214 (columns)
-    float y = __builtin_fmaf(u.m[7], b, __builtin_fmaf(u.m[4], g, u.m[1] * r));
-    float z = __builtin_fmaf(u.m[8], b, __builtin_fmaf(u.m[5], g, u.m[2] * r));
-    r = x * u.em; g = y * u.em; b = z * u.em;                          // :217-218
-    float L = rd_dot709_c(r, g, b);                                    // :222
-    float hl = __builtin_fmaf(L, u.highlights, 1.0f);                  // :226
-    r = r * hl; g = g * hl; b = b * hl;
-    float sh = __builtin_fmaf(1.0f - L, u.shadows, 1.0f);              // :230
-    r = r * sh; g = g * sh; b = b * sh;
-    r = __builtin_fmaf(r - 0.5f, u.cf, 0.5f);                          // :233-234
-    g = __builtin_fmaf(g - 0.5f, u.cf, 0.5f);
-    b = __builtin_fmaf(b - 0.5f, u.cf, 0.5f);
-    r = (r - u.blacks) * u.rden;                                       // :239
-    g = (g - u.blacks) * u.rden;
-    b = (b - u.blacks) * u.rden;
-    float Y = rd_dot709_c(r, g, b);                                    // :243
-    float ys = Y * u.oms;                                              // :247
-    r = __builtin_fmaf(r, u.s, ys); g = __builtin_fmaf(g, u.s, ys); b = __builtin_fmaf(b, u.s, ys);
-    float sat = __builtin_fmaxf(r, __builtin_fmaxf(g, b)) - __builtin_fminf(r, __builtin_fminf(g, b)); // :251
-    float a2 = __builtin_fmaf(u.vibrance, 1.0f - sat, 1.0f);           // :254, :257
-    float Y2 = rd_dot709_c(r, g, b);                                   // :256
-    float yv = Y2 * (1.0f - a2);
-    r = __builtin_fmaf(r, a2, yv); g = __builtin_fmaf(g, a2, yv); b = __builtin_fmaf(b, a2, yv);
-    rd_rgb o;                                                          // :261-264
-    o.r = rd_gamma_clamp(r);
-    o.g = rd_gamma_clamp(g);
-    o.b = rd_gamma_clamp(b);
-    return o;
-}
-
-template <int MATH>
-__device__ __forceinline__ rd_rgb rd_colour_m(const rd_ku &u, float r, float g, float b)
-{
-    return MATH == RD_MATH_CONTRACTED ? rd_colour_c(u, r, g, b) : rd_colour(u, r, g, b);
-}
-
-// The export kernel's form of the two functions above: N colour triples advanced together, stage by stage, each triple
-// seeing exactly the operation sequence of rd_colour / rd_colour_c, and every stage that u.elide (rd_uniforms.h) marks as
-// an exact identity for this frame's uniforms skipped behind ONE wave-uniform branch for all N.  With all sliders away
+// shaders.rs:192-266 on N demosaiced triples, advanced together stage by stage.  MATH = RD_MATH_STRICT: the literal
+// operation order of the WGSL text (this TU is compiled with -ffp-contract=off, so nothing fuses; the divide is the
+// IEEE-correct one).  MATH = RD_MATH_CONTRACTED: the same text with every a*b+c contracted to one fma and the levels
+// division done as x*RN(1/d) -- the lowering an AMD shader compiler applies to the reference's WGSL (DESIGN.md section
+// 3b; oracle: colour_stack_contracted); ~62 VALU + 3 pow per triple instead of ~105 + 3 pow.  Every stage that u.elide
+// (rd_uniforms.h) marks as an exact identity for this frame's uniforms is skipped behind ONE wave-uniform branch for all N.  With all sliders away
 // from their defaults nothing is skipped; a typical edit (identity matrix -- the reference never passes another one --
 // and a few untouched sliders) sheds a quarter of the linear part.  Results are written back into r, g, b.
 template <int N, int MATH>
@@ -220,7 +134,7 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
     if (C) {
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = r[i] * u.rden; g[i] = g[i] * u.rden; b[i] = b[i] * u.rden; }
-    } else if (u.fast_div) {                                     // rd_div_den for all 3N values behind ONE pair of branches
+    } else if (u.fast_div) {                                     // the reciprocal-correction divide (above) for all 3N values
         float q[3 * N];
 #pragma unroll
         for (int i = 0; i < N; ++i) { q[3 * i] = r[i]; q[3 * i + 1] = g[i]; q[3 * i + 2] = b[i]; }
@@ -276,6 +190,14 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) { r[i] = rd_gamma_clamp(r[i]); g[i] = rd_gamma_clamp(g[i]); b[i] = rd_gamma_clamp(b[i]); }   // :261-264
+}
+
+template <int MATH>
+__device__ __forceinline__ rd_rgb rd_colour_m(const rd_ku &u, float r, float g, float b)      // one triple
+{
+    float tr[1] = { r }, tg[1] = { g }, tb[1] = { b };
+    rd_colour_n<1, MATH>(u, tr, tg, tb);
+    return rd_rgb{ tr[0], tg[0], tb[0] };
 }
 
 // f32(raw)/4096 (shaders.rs:106-110, :167-168) with the optional integer black level.

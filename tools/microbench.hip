@@ -64,7 +64,7 @@ mb_quads(const uint16_t *__restrict__ cfa, float *__restrict__ out, uint32_t W, 
         rd_rgb c1, c2, c3;
         if (MODE & M_LITE) { c1 = mb_colour_lite(u, C, A, B, 1); c2 = mb_colour_lite(u, C, D, A, 1); c3 = mb_colour_lite(u, C, D, B, 1); }
         else if (MODE & M_LITE2) { c1 = mb_colour_lite(u, C, A, B, 0); c2 = mb_colour_lite(u, C, D, A, 0); c3 = mb_colour_lite(u, C, D, B, 0); }
-        else if (COMPUTE) { c1 = rd_colour(u, C, A, B); c2 = rd_colour(u, C, D, A); c3 = rd_colour(u, C, D, B); }
+        else if (COMPUTE) { c1 = rd_colour_m<0>(u, C, A, B); c2 = rd_colour_m<0>(u, C, D, A); c3 = rd_colour_m<0>(u, C, D, B); }
         else { c1 = { C, A, B }; c2 = { C, D, A }; c3 = { C, D, B }; }
         if (HIST) {
             rd_hist_add(lh, copy, rd_q8(c1.r), rd_q8(c1.g), rd_q8(c1.b), 2u);
