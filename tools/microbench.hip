@@ -375,6 +375,9 @@ int main(int argc, char **argv)
     PROD("PRODUCT f16 hist x256 BURST", 1, true, 256, true, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT f16 nohist x512", 1, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     PROD("PRODUCT u8 hist x256", 2, true, 256, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT u8 hist x512", 2, true, 512, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT f16 hist x512", 1, true, 512, false, (uint32_t *)nullptr, slab64);
+    PROD("PRODUCT rgb8 hist x512", 3, true, 512, false, (uint32_t *)nullptr, slab64);
     PROD("PRODUCT u8 nohist x512", 2, false, 512, false, (uint32_t *)nullptr, (unsigned long long *)nullptr);
 #define SPAT(NAME, ROWS, NT, LOADS, BLOCKS) vs.push_back({ NAME, [&](int k) { hipLaunchKernelGGL((mb_store_pat<ROWS, NT, LOADS>), dim3(BLOCKS), dim3(1024), 0, s, din[k % NIN], dout[k % NOUT], W, H); }, {} })
     SPAT("pat 2rows nt loads x512", 2, true, true, 512);
