@@ -93,6 +93,12 @@ void rd_edit_params_default(rd_edit_params *p);
 int rd_derived_dims(uint32_t width, uint32_t height, uint32_t *preview_w, uint32_t *preview_h,
                     uint32_t *hist_w, uint32_t *hist_h);
 size_t rd_format_bytes_per_pixel(uint32_t format); /* 0 for an unknown format */
+/* Diagnostic (no device needed): the steps of the colour stack the export kernel will skip for these uniforms because
+ * they are exact identities (bit mask, 1 = temperature/tint, 2 = identity matrix, 4 = exposure, 8 = highlights,
+ * 16 = shadows, 32 = saturation, 64 = vibrance, 128 = divide fix-up, 256 = blacks).  Results never
+ * depend on it. */
+uint32_t rd_elided_steps(const rd_edit_params *params, const float wb_multipliers[4], const float color_matrix[9],
+                         uint32_t math_mode);
 
 /* ---- RenderPipeline ------------------------------------------------------------------------ */
 /* RenderPipeline::new (pipeline.rs:114-363).  `cfa` is w*h u16, row-major, no padding

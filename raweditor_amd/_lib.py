@@ -51,6 +51,7 @@ PROTOTYPES = {
     "rd_edit_params_default": (None, [C.POINTER(RdEditParams)]),
     "rd_derived_dims": (_I, [_U32, _U32] + [C.POINTER(_U32)] * 4),
     "rd_format_bytes_per_pixel": (_SZ, [_U32]),
+    "rd_elided_steps": (_U32, [C.POINTER(RdEditParams), C.POINTER(C.c_float), C.POINTER(C.c_float), _U32]),
     "rd_pipeline_create": (_I, [_I, C.c_int64, _VP, _U32, _U32, C.POINTER(RdEditParams),
                                 C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_VP)]),
     "rd_pipeline_create_from_device": (_I, [_I, C.c_int64, _VP, _U32, _U32, C.POINTER(RdEditParams),

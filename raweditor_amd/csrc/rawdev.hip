@@ -84,6 +84,12 @@ extern "C" size_t rd_format_bytes_per_pixel(uint32_t f)
     return f == RD_FMT_RGBA_F32 ? 16 : f == RD_FMT_RGBA_F16 ? 8 : f == RD_FMT_RGBA_U8 ? 4 : f == RD_FMT_RGB_U8 ? 3 : 0;
 }
 
+extern "C" uint32_t rd_elided_steps(const rd_edit_params *p, const float wb[4], const float cm[9], uint32_t math_mode)
+{
+    if (!p || !wb || !cm) return 0u;
+    return rd_make_ku(*p, wb, cm, 1.0f, 0.0f, 0.0f, 0u, math_mode).elide;
+}
+
 // ------------------------------------------------------------------------------------------------
 // device bookkeeping
 // ------------------------------------------------------------------------------------------------

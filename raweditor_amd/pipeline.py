@@ -40,6 +40,20 @@ def derived_dims(width: int, height: int) -> Tuple[int, int, int, int]:
     return tuple(x.value for x in v)
 
 
+ELIDED_STEP_NAMES = {1: "temperature/tint", 2: "matrix", 4: "exposure", 8: "highlights", 16: "shadows", 32: "saturation",
+                     64: "vibrance", 128: "divide fix-up", 256: "blacks"}
+
+
+def elided_steps(params: EditParams, wb_multipliers: Sequence[float], color_matrix: Sequence[float],
+                 math_mode: int = 0) -> int:
+    """Bit mask of the colour-stack steps the export kernel skips for these uniforms (exact identities; diagnostic,
+    needs no device).  See ELIDED_STEP_NAMES and DESIGN.md section 4."""
+    wb = (C.c_float * 4)(*[float(x) for x in wb_multipliers])
+    cm = (C.c_float * 9)(*[float(x) for x in color_matrix])
+    cp = params.to_c()
+    return int(_lib.lib().rd_elided_steps(C.byref(cp), wb, cm, int(math_mode)))
+
+
 class RenderPipeline:
     """Owns one CFA plane in HBM plus the current uniforms (EditParams, wb, matrix, zoom/pan)."""
 

@@ -171,3 +171,33 @@ def test_export_kernel_register_budget():
     import pytest
     with pytest.raises(RuntimeError):
         build.check_resources({"rd_develop_quads<x>": {"vgprs": 72, "sgprs": 78, "scratch": 0}})
+
+
+def test_elided_steps_flags():
+    """Host-side proof logic of the identity-step elision (rd_uniforms.h RD_EL_*), no device needed: untouched sliders
+    and the identity matrix are flagged, touched ones are not, and nothing that relies on finiteness is flagged when an
+    intermediate of the stack could overflow."""
+    import raweditor_amd as ra
+    ident = (1, 0, 0, 0, 1, 0, 0, 0, 1)
+    cam = (1.6, -0.4, -0.2, -0.3, 1.5, -0.2, 0.0, -0.5, 1.5)
+    wb = (2.0, 1.0, 1.5, 1.0)
+    K, MAT, EM, HL, SH, SAT, VIB, FIX, BLK = 1, 2, 4, 8, 16, 32, 64, 128, 256
+    for math in (0, 1):
+        f = ra.elided_steps(ra.EditParams(), wb, ident, math)
+        assert f == K | MAT | EM | HL | SH | SAT | VIB | FIX | BLK
+        assert ra.elided_steps(ra.EditParams(), wb, cam, math) == f & ~MAT
+        full = ra.EditParams(exposure=0.7, contrast=5.0, highlights=-0.4, shadows=0.3, whites=1.05, blacks=0.02,
+                             vibrance=0.4, saturation=25.0, temperature=0.25, tint=-0.15)
+        assert ra.elided_steps(full, wb, cam, math) == FIX
+        assert ra.elided_steps(full, wb, ident, math) == FIX | MAT
+        assert ra.elided_steps(ra.EditParams(tint=0.1), wb, ident, math) == f & ~K
+        assert ra.elided_steps(ra.EditParams(saturation=-100.0), wb, ident, math) == f & ~SAT
+        # overflow guards: x*1 cases stay (exact for every x), everything that needs a finite operand is dropped
+        big = ra.elided_steps(ra.EditParams(exposure=120.0), wb, ident, math)
+        assert big == K | BLK, big
+        assert ra.elided_steps(ra.EditParams(), (1e38, 1.0, 1.0, 1.0), ident, math) == K | EM | BLK
+        # a denominator outside the normal range switches the reciprocal divide off, and with it the flags behind it
+        tiny = ra.elided_steps(ra.EditParams(whites=0.0, blacks=0.0001), wb, ident, math)
+        assert not tiny & (FIX | SAT | VIB) and tiny & MAT
+        nan = ra.elided_steps(ra.EditParams(highlights=float("nan")), wb, ident, math)
+        assert not nan & HL
