@@ -1,4 +1,4 @@
-"""Per-launch time of the export path (256 x 24 MP, f32 surface + histogram) for slider stacks with more or fewer
+"""Per-launch time of the export path (256 x 24 MP, surface f32 | f16 | u8 = argv[1], + histogram) for slider stacks with more or fewer
 untouched sliders: shows what the exact identity-step elision (rd_uniforms.h: RD_EL_*) buys on realistic edits.
 RD_NO_ELIDE=1 in the environment switches the elision off for an A/B in a second process."""
 import os
@@ -15,12 +15,15 @@ WB = (2.0, 1.0, 1.5, 1.0)
 IDENT = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
 CM = (1.6, -0.4, -0.2, -0.3, 1.5, -0.2, 0.0, -0.5, 1.5)
 NF, NIN, NOUT = 256, 32, 8
+FMT_NAME = sys.argv[1] if len(sys.argv) > 1 else "f32"
 
 
 def main():
     rng = np.random.default_rng(1)
     ins = [DevBuf.from_array(rng.integers(0, 4096, (H, W), dtype=np.uint16)) for _ in range(NIN)]
-    outs = [DevBuf(H * W * 16) for _ in range(NOUT)]
+    fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8}[FMT_NAME]
+    outs = [DevBuf(H * W * ra.BYTES_PER_PIXEL[fmt]) for _ in range(NOUT)]
+    print(f"surface {FMT_NAME}, fused histogram on, {NF} frames of {W}x{H}")
     stacks = {
         "all sliders default, identity matrix": (lambda i: ra.EditParams(), IDENT),
         "exposure + contrast + whites/blacks, identity matrix": (lambda i: ra.EditParams(exposure=0.7, contrast=5.0, whites=1.05, blacks=0.02), IDENT),
@@ -29,7 +32,7 @@ def main():
         "all ten sliders randomised, camera matrix (bench.py)": (lambda i: ra.EditParams.random(np.random.default_rng([7, i])), CM),
     }
     for name, (mk, cm) in stacks.items():
-        be = ra.BatchExporter(0, W, H, ra.FMT_RGBA_F32, True)
+        be = ra.BatchExporter(0, W, H, fmt, True)
         fr = be.make_frames([ins[i % NIN].ptr for i in range(NF)], [outs[i % NOUT].ptr for i in range(NF)], [mk(i) for i in range(NF)], WB, cm)
         be.develop(fr); sync()
         ts = []
