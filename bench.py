@@ -101,6 +101,43 @@ def cpu_baseline(width, height, budget_s):
                       f"{el:.1f} s on {cores} threads ({model})"}
 
 
+def verify_outputs(ra, fmt_name, W, H, cfas, params, ring, n_frames, row_bands, math_name):
+    """Outside the timed region: download two surfaces of the output ring as the timed passes left them and compare
+    four row bands of each with the oracle, bit for bit (the histogram sum alone would pass for garbage pixels).
+    Slot s of the ring was last written by frame n_frames - len(ring) + s (frames go to slot i % len(ring))."""
+    import numpy as np
+    from oracle import ref_c                       # the checker, never the thing measured
+    from raweditor_amd import FIELDS
+    math_mode = ref_c.MATH_CONTRACTED if math_name == "contracted" else ref_c.MATH_STRICT
+    mid = (H // 2) | 1
+    bands = [(0, min(6, H)), (max(0, min(1001, H - 6)), min(1007, H)), (mid, min(mid + 2, H)), (max(0, H - 6), H)]
+    nring = len(ring)
+    checked = []
+    for slot in sorted({0, nring - 1}):
+        owners = [i for i in range(n_frames) if i % nring == slot]
+        if not owners:
+            continue
+        i = owners[-1]
+        cfa = cfas[i].cpu().numpy().view(np.uint16)
+        u = ref_c.make_uniforms({f: getattr(params[i], f) for f in FIELDS}, WB, CM, math_mode=math_mode)
+        raw = ring[slot].cpu().numpy()
+        for r0, r1 in bands:
+            exp = ref_c.render_band(cfa, u, r0, r1)
+            if fmt_name == "f32":
+                got = raw.view(np.float32).reshape(H, W, 4)[r0:r1]
+                ok = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+            elif fmt_name == "f16":
+                got = raw.view(np.uint16).reshape(H, W, 4)[r0:r1]
+                ok = np.array_equal(got, ref_c.pack_f16(exp).view(np.uint16))
+            else:
+                got = raw.reshape(H, W, 4)[r0:r1]
+                ok = np.array_equal(got, ref_c.pack_u8(exp))
+            if not ok:
+                return False, f"frame {i} (ring slot {slot}) rows {r0}..{r1} differ from the oracle"
+        checked.append(i)
+    return True, f"frames {checked}: {len(bands)} row bands each bit-identical to the oracle"
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -191,14 +228,29 @@ def main():
         got = int(hist.sum().item())
         assert got == 3 * world * F * W * H, f"histogram sum {got} != {3 * world * F * W * H}"
 
+    verified, verified_note = None, "not checked"
+    if rank == 0:                                          # outside the timed region
+        try:
+            verified, verified_note = verify_outputs(ra, args.format, W, H, cfas, params, ring, F, args.row_bands, args.math)
+        except Exception as e:  # noqa: BLE001  (oracle not built / not shipped: say so, do not claim)
+            verified, verified_note = None, f"oracle check unavailable: {e}"
+
     launches = args.steps * F * max(1, args.row_bands)
     launch_us = dev_ms * 1e3 / launches                    # avg fused-launch duration incl. gaps
     alg_bytes = BYTES_PER_PX[args.format] * W * H / max(1, args.row_bands)
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9        # GB/s
-    traffic = None
-    try:                                                   # PMC-derived HBM bytes per launch (rocprofv3 --pmc,
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:   # tools/parse_pmc.py)
-            traffic = json.load(fh).get(args.format, {}).get("hbm_bytes_per_launch")
+    # HBM bytes per launch: NOT measured by this run.  It is the PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # passes, tools/gpu_pmc.sh + tools/parse_pmc.py) of the committed profile for this surface format, when the
+    # profile was taken on the same frame size / band count; otherwise null.
+    traffic, traffic_source = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            prof = json.load(fh)
+        key = args.format if args.row_bands <= 1 else f"{args.format}_bands{args.row_bands}"
+        ent = prof.get(key, {})
+        if ent and list(ent.get("frame", prof.get("frame", []))) == [W, H]:
+            traffic = ent.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/pmc_traffic.json[{key}] ({prof.get('tag', 'committed profile')}), not this run"
     except (OSError, ValueError):
         pass
 
@@ -213,8 +265,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32",                                    # the arithmetic type of the path for EVERY surface format
         "data": "synthetic",
+        "verified": verified,
+        "verified_note": verified_note,
         "config": {
             "workload": f"BASELINE configs[2]: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
                         f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}, "
@@ -226,7 +280,10 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": "rd_develop_quads", "launch_us": round(launch_us, 2),
+            "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
+                              "includes inter-launch gaps and the histogram folds (conservative)",
             "algorithmic_bytes_per_launch": int(alg_bytes),
         },
     }
