@@ -6,7 +6,7 @@ also config 4's share): a batch of 256 distinct synthetic 24 MP RGGB frames (601
 uniform 12-bit, seed 0x52415745) resident in HBM, one randomised slider stack per frame drawn from
 the UI ranges, wb = (2, 1, 1.5), non-identity colour matrix, RGBA-f32 surface written to a ring of
 output buffers, fused 3x256 histogram accumulated in u64.  One "step" = one pass over the batch:
-256 fused launches + the histogram fold (+ one RCCL all-reduce of 768 x i64 when N > 1).
+the fused launches of rd_batch_develop (up to 8 frames each) + the histogram fold (+ one RCCL all-reduce of 768 x i64 when N > 1).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -235,9 +235,14 @@ def main():
         except Exception as e:  # noqa: BLE001  (oracle not built / not shipped: say so, do not claim)
             verified, verified_note = None, f"oracle check unavailable: {e}"
 
-    launches = args.steps * F * max(1, args.row_bands)
-    launch_us = dev_ms * 1e3 / launches                    # avg fused-launch duration incl. gaps
-    alg_bytes = BYTES_PER_PX[args.format] * W * H / max(1, args.row_bands)
+    # One rd_batch_develop call = `lpc` fused launches (the library packs up to 8 consecutive frames into one launch;
+    # RD_BATCH_PERSISTENT=0 gives one launch per frame / row band).  Algorithmic bytes per launch = SURVEY 8(d)'s
+    # per-pixel figure x the pixels one launch processes.
+    lpc = max(1, be.last_launch_count())
+    launches = args.steps * lpc
+    launch_us = dev_ms * 1e3 / launches                    # avg fused-launch period incl. gaps and folds
+    frame_us = dev_ms * 1e3 / (args.steps * F)
+    alg_bytes = BYTES_PER_PX[args.format] * W * H * F / lpc
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9        # GB/s
     # HBM bytes per launch: NOT measured by this run.  It is the PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # passes, tools/gpu_pmc.sh + tools/parse_pmc.py) of the committed profile for this surface format, when the
@@ -248,8 +253,8 @@ def main():
             prof = json.load(fh)
         key = args.format if args.row_bands <= 1 else f"{args.format}_bands{args.row_bands}"
         ent = prof.get(key, {})
-        if ent and list(ent.get("frame", prof.get("frame", []))) == [W, H]:
-            traffic = ent.get("hbm_bytes_per_launch")
+        if ent and list(ent.get("frame", prof.get("frame", []))) == [W, H] and ent.get("hbm_bytes_per_frame"):
+            traffic = int(ent["hbm_bytes_per_frame"] * F / lpc)             # per launch, like `achieved`
             traffic_source = f"profiles/pmc_traffic.json[{key}] ({prof.get('tag', 'committed profile')}), not this run"
     except (OSError, ValueError):
         pass
@@ -274,14 +279,15 @@ def main():
                         f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}, "
                         f"{args.math} f32 arithmetic",
             "frames_per_gpu": F, "width": W, "height": H, "surface": f"rgba_{args.format}",
-            "row_bands": args.row_bands, "out_ring": len(ring), "math_mode": args.math,
+            "row_bands": args.row_bands, "out_ring": len(ring), "math_mode": args.math, "launches_per_step": lpc,
             "parallelism": f"frames sharded round-robin over {world} GPU(s); RCCL all-reduce of i64[768] histogram only",
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": "rd_develop_quads", "launch_us": round(launch_us, 2),
+            "kernel": "rd_develop_batch" if lpc < F * max(1, args.row_bands) else "rd_develop_quads",
+            "launch_us": round(launch_us, 2), "frames_per_launch": round(F / lpc, 3), "us_per_frame": round(frame_us, 2),
             "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
                               "includes inter-launch gaps and the histogram folds (conservative)",
             "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -303,10 +309,10 @@ def main():
                     be2.histogram(hist.data_ptr(), stream=stream.cuda_stream)
             e1.record(stream)
             torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (5 * F * max(1, args.row_bands))
-        ach = alg_bytes / (us * 1e-6) / 1e9
-        result["alt_math"] = {"math_mode": other, "value": round(W * H / max(1, args.row_bands) / us, 1), "unit": "MP/s",
-                              "launch_us": round(us, 2), "achieved_GBps": round(ach, 1),
+        us = e0.elapsed_time(e1) * 1e3 / (5 * F)         # per frame
+        ach = BYTES_PER_PX[args.format] * W * H / (us * 1e-6) / 1e9
+        result["alt_math"] = {"math_mode": other, "value": round(W * H / us, 1), "unit": "MP/s",
+                              "us_per_frame": round(us, 2), "achieved_GBps": round(ach, 1),
                               "frac": round(ach / HBM_PEAK_GBPS, 4)}
         be2.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RD_ABI_VERSION 1
+#define RD_ABI_VERSION 2
 
 typedef enum rd_status {
     RD_OK = 0,
@@ -170,12 +170,20 @@ int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format
                     uint32_t with_histogram, rd_batch **out);
 void rd_batch_destroy(rd_batch *b);
 int rd_batch_set_math_mode(rd_batch *b, uint32_t math_mode); /* rd_math_mode, default RD_MATH_STRICT */
-/* Enqueue one fused demosaic+develop(+histogram) launch per frame on `stream`, full resolution,
- * zoom 1 / pan 0 (the export map).  Histogram counts accumulate inside the context in u64.
- * `row_bands` > 1 splits every frame into that many row-band launches (config 5's tiled
- * multi-launch); 0 or 1 = one launch per frame.  Not synchronised. */
+/* Enqueue the fused demosaic+develop(+histogram) of `n_frames` frames on `stream`, full resolution, zoom 1 / pan 0
+ * (the export map).  Histogram counts accumulate inside the context in u64.  Not synchronised.
+ * Launches: by default ONE launch covers several consecutive frames of the call (up to 8, RD_BATCH_MAX_FRAMES; the
+ * kernel's tile tickets, uniforms and surface pointers change frame inside the launch, so there is no drain / refill
+ * between frames).  A launch never holds two frames whose surfaces overlap, so the surfaces of one call are always
+ * written in call order where they alias (an output ring).  The frame array is copied before the call returns.
+ * `row_bands` is config 5's "tiled multi-launch per frame": with multi-frame launches it needs no launches of its own
+ * (the ticket front sweeps a frame in row order; a band is a range of tickets) and is ignored; with
+ * RD_BATCH_PERSISTENT=0 in the environment every frame is `row_bands` separate row-band launches (0 or 1 = one launch
+ * per frame), as in ABI version 1. */
 int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n_frames, uint32_t row_bands,
                      void *stream);
+/* Number of fused kernel launches the last rd_batch_develop call on this context enqueued (measurement aid). */
+uint32_t rd_batch_last_launch_count(const rd_batch *b);
 /* Reduce the accumulated histogram into `hist_dev` (768 x u64 on the device: R[256] G[256] B[256])
  * and reset the accumulator.  Enqueued on `stream`; the multi-GPU sum is the caller's all-reduce. */
 int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);

@@ -9,6 +9,7 @@ import sys
 from .build import LIB_PATH
 
 RD_OK = 0
+ABI_VERSION = 2          # include/rawdev.h RD_ABI_VERSION
 FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8, FMT_RGB_U8 = 0, 1, 2, 3
 MATH_STRICT, MATH_CONTRACTED = 0, 1
 BYTES_PER_PIXEL = {FMT_RGBA_F32: 16, FMT_RGBA_F16: 8, FMT_RGBA_U8: 4, FMT_RGB_U8: 3}
@@ -72,6 +73,7 @@ PROTOTYPES = {
     "rd_batch_destroy": (None, [_VP]),
     "rd_batch_set_math_mode": (_I, [_VP, _U32]),
     "rd_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32, _VP]),
+    "rd_batch_last_launch_count": (_U32, [_VP]),
     "rd_batch_histogram": (_I, [_VP, _VP, _VP]),
     "rd_exporter_create": (_I, [_I, _U32, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),
     "rd_exporter_destroy": (None, [_VP]),
@@ -119,8 +121,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        if L.rd_abi_version() != 1:
-            raise RawdevError(-5, f"ABI version {L.rd_abi_version()} != 1")
+        if L.rd_abi_version() != ABI_VERSION:
+            raise RawdevError(-5, f"ABI version {L.rd_abi_version()} != {ABI_VERSION}")
         _lib = L
     return _lib
 

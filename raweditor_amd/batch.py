@@ -67,9 +67,13 @@ class BatchExporter:
         return arr
 
     def develop(self, frames, row_bands: int = 1, stream: int = 0) -> None:
-        """Enqueue one launch per frame (per row band) on `stream`; not synchronised."""
+        """Enqueue the frames on `stream` (multi-frame launches by default, see rd_batch_develop); not synchronised."""
         check(_lib.lib().rd_batch_develop(self._h, frames, len(frames), int(row_bands),
                                           C.c_void_p(stream) if stream else None))
+
+    def last_launch_count(self) -> int:
+        """Fused kernel launches the last develop() enqueued (multi-frame launches cover up to 8 frames each)."""
+        return int(_lib.lib().rd_batch_last_launch_count(self._h))
 
     def histogram(self, hist_dev: int, stream: int = 0) -> None:
         """Fold the accumulated counts into a device u64[768] and reset the accumulator."""

@@ -100,7 +100,7 @@ def check_resources(res: dict) -> None:
     """Every instance of the export kernel must keep the two-workgroups-per-CU budget (see LIMITS)."""
     bad = []
     for name, r in res.items():
-        if "rd_develop_quads" not in name:
+        if "rd_develop_quads" not in name and "rd_develop_batch" not in name:
             continue
         for k, lim in LIMITS.items():
             if r.get(k, 0) > lim:

@@ -34,6 +34,10 @@
 typedef float rd_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rd_u2 __attribute__((ext_vector_type(2)));
 typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
+// Frame pointers that a multi-frame launch reads from its descriptor array carry no address space of their own (hipcc
+// would emit flat_load / flat_store for them, which count in vmcnt AND lgkmcnt and retire out of order: every wait
+// becomes vmcnt(0)).  All pixel traffic therefore goes through explicitly global pointers.
+#define RD_GLOBAL __attribute__((address_space(1)))
 
 struct rd_rgb { float r, g, b; };
 
@@ -343,30 +347,59 @@ template <> struct rd_tile_out<RD_FMT_RGB_U8> { uint32_t v1, v2, v3; };         
 __device__ uint32_t rd_probe_buf[RD_MAX_BLOCKS * 8];
 #endif
 
-template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
-__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
-rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
-                 uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k,
-                 uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
+// One frame of a multi-frame launch (rd_develop_batch below): what a single-frame launch gets as kernel arguments.
+// The host (rawdev.hip, rd_batch_develop) fills an array of these in HBM; a wave reads an entry with scalar loads
+// when its tile stream crosses into that frame.
+struct alignas(64) rd_frame_desc {
+    const uint16_t *cfa;
+    void *out;
+    rd_ku u;
+    uint32_t pad_[48 - 4 - sizeof(rd_ku) / 4];
+};
+static_assert(sizeof(rd_frame_desc) == 192, "rd_frame_desc is three 64-byte lines");
+
+// MULTI = false: one frame (or one row band: units [unit0, unit1)) per launch, uniforms in kernel arguments.
+// MULTI = true : the launch covers `nframes` whole frames of one size (descs[0 .. nframes-1]); the tile index runs
+//                through all of them (frame-major), so the ticket front moves from one frame into the next without
+//                a launch boundary -- no drain tail, no inter-launch gap, and the next frame's first tiles are
+//                computed while the previous frame's last ones are still being stored.  A wave re-reads the
+//                uniforms (scalar loads, ~190 B) only when its compute stage changes frame: about once per
+//                (tiles per frame / resident waves) = 11 tiles at 24 MP.
+template <int FMT, bool HIST, bool FULL, int MATH, bool BURST, bool MULTI>
+__device__ __forceinline__ void
+rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, uint32_t W, uint32_t H, uint32_t unit0,
+              uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
+              const rd_ku &u_arg, uint32_t *slab32, unsigned long long *slab64,
+              const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t tpf, uint32_t tpf_magic, uint32_t pf_thr)
 {
     // Register budget: two workgroups per CU need <= 80 SGPRs AND <= 64 VGPRs per wave (RD_NUM_SGPR above).  The uniforms of
     // the front of the stack (white balance, temperature/tint, matrix) and of the levels divide (17 values) are therefore parked in VGPRs -- the asm
     // keeps the compiler from folding them back into scalar operands -- which leaves the kernel at ~62 SGPRs / ~60 VGPRs
     // with no spill.  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
     // that is not what limits this kernel: DESIGN.md section 6.)
-    rd_ku u = u_arg;
-#define RD_PARK(f) asm volatile("v_mov_b32 %0, %1" : "=v"(u.f) : "s"(u_arg.f))
-    RD_PARK(wb_r); RD_PARK(wb_g); RD_PARK(wb_b); RD_PARK(kr); RD_PARK(kg); RD_PARK(kb);
-    RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
-    RD_PARK(den); RD_PARK(rden);                                 // 36 uses per tile in the divide's FMA chains
-    if constexpr (FMT != RD_FMT_RGBA_F32) {                      // the narrower surfaces carry fewer live VGPRs: park six more
-        RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
-    }
+    rd_ku u;
+    auto adopt = [&](const rd_ku &src_mem) {                     // take over one frame's uniforms (MULTI: on every frame change)
+        rd_ku src = src_mem;
+        if constexpr (MULTI) {                                   // descriptor fields: have every scalar load issued and landed
+            asm volatile("" : "+s"(src.wb_r), "+s"(src.wb_g), "+s"(src.wb_b), "+s"(src.kr), "+s"(src.kg), "+s"(src.kb),   // before the
+                              "+s"(src.m[0]), "+s"(src.m[1]), "+s"(src.m[2]), "+s"(src.m[3]), "+s"(src.m[4]), "+s"(src.m[5]),  // first park
+                              "+s"(src.m[6]), "+s"(src.m[7]), "+s"(src.m[8]), "+s"(src.den), "+s"(src.rden));                // (one round trip, not 17)
+        }
+        u = src;
+#define RD_PARK(f) asm volatile("v_mov_b32 %0, %1" : "=v"(u.f) : "s"(src.f))
+        RD_PARK(wb_r); RD_PARK(wb_g); RD_PARK(wb_b); RD_PARK(kr); RD_PARK(kg); RD_PARK(kb);
+        RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
+        RD_PARK(den); RD_PARK(rden);                             // 36 uses per tile in the divide's FMA chains
+        if constexpr (FMT != RD_FMT_RGBA_F32) {                  // the narrower surfaces carry fewer live VGPRs: park six more
+            RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
+        }
 #undef RD_PARK
+    };
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[(FMT == RD_FMT_RGBA_F32 || BURST) ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
+    __shared__ rd_f4 pf_dump[(BURST && MULTI) ? 64 : 1];         // where the later frames' sweep lands (never read)
     if (HIST) rd_hist_zero(lh);
 #ifdef RD_PROBE
     const uint64_t probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
@@ -377,7 +410,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qpr = W >> 1;                                 // quads per unit
-    const uint32_t ntiles = (unit1 - unit0) * tpu;               // < 2^32: checked on the host
+    const uint32_t ntiles = MULTI ? nframes * tpf : (unit1 - unit0) * tpu;   // < 2^32: checked on the host
     const uint32_t nwaves = gridDim.x * RD_WAVES;
     const uint32_t copy = lane & (RD_HK - 1);
     // First tile: static, slot = wave_in_block * gridDim + block (block-cyclic, so a launch smaller than the grid is
@@ -413,8 +446,28 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             if (t < ntiles) return t;                            // only ticket tmax-1 can point past the end
         }
     };
-    uint32_t unit, qt;
-    split(tile, unit, qt);
+    // MULTI: global tile -> (frame, tile in frame) the same way, then split().
+    auto locate = [&](uint32_t t, uint32_t &fr, uint32_t &tin, uint32_t &un, uint32_t &q) {
+        if (MULTI) {
+            uint32_t d = __umulhi(t, tpf_magic);
+            uint32_t r = t - d * tpf;
+            if (r >= tpf) { d += 1u; r -= tpf; }
+            fr = d; t = r;
+        } else {
+            fr = 0u;
+        }
+        tin = t;
+        split(t, un, q);
+    };
+    uint32_t unit, qt, fr_c, tin0;
+    locate(tile < ntiles ? tile : 0u, fr_c, tin0, unit, qt);
+    // The three pipeline stages (load next / compute current / store previous) may sit in three different frames:
+    // cfa_n, (u, out_c), out_p.
+    const RD_GLOBAL uint16_t *cfa = (const RD_GLOBAL uint16_t *)(MULTI ? descs[fr_c].cfa : cfa_arg);     // load stage
+    RD_GLOBAL void *out_c = (RD_GLOBAL void *)(MULTI ? descs[fr_c].out : out_arg);   // compute stage's surface; becomes the store stage's
+    adopt(MULTI ? descs[fr_c].u : u_arg);
+    uint32_t fr_n = fr_c;
+    (void)tin0;
 
     // cfa[ra][2q..2q+1] and cfa[rb][2q..2q+1] of tile (pu, pq) for this lane; rows clamped to the image.
     auto load_tile = [&](uint32_t pu, uint32_t pq, uint32_t &top, uint32_t &bot) {
@@ -422,8 +475,8 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
         if (!FULL) q = q < qpr ? q : qpr - 1u;                   // clamp: loaded but never used
         const uint32_t ra = pu ? 2u * pu - 1u : 0u;
         const uint32_t rb = 2u * pu < H ? 2u * pu : H - 1u;
-        top = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W)[q];
-        bot = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W)[q];
+        top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W)[q];
+        bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)rb * W)[q];
     };
 
     // demosaic + colour stack + histogram of one tile -> packed results
@@ -475,7 +528,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
 
     // surface stores of one tile.  A missing row (first / last unit) is redirected onto the existing
     // one with that row's value, so the number of store instructions never depends on the tile.
-    auto store_tile = [&](uint32_t tu, uint32_t tq, const rd_tile_out<FMT> &r) {
+    auto store_tile = [&](RD_GLOBAL void *out, uint32_t tu, uint32_t tq, const rd_tile_out<FMT> &r) {
         const bool has_a = tu != 0u, has_b = 2u * tu < H;
         const size_t row_b_px = (size_t)(has_b ? 2u * tu : 2u * tu - 1u) * W;
         const size_t row_a_px = has_a ? (size_t)(2u * tu - 1u) * W : row_b_px;
@@ -487,7 +540,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             st[lane * 3u + 1u] = rd_f4{ r.c2.r, r.c2.g, r.c2.b, 1.0f };
             st[lane * 3u + 2u] = rd_f4{ r.c3.r, r.c3.g, r.c3.b, 1.0f };
             __builtin_amdgcn_wave_barrier();
-            rd_f4 *o = reinterpret_cast<rd_f4 *>(out);
+            RD_GLOBAL rd_f4 *o = reinterpret_cast<RD_GLOBAL rd_f4 *>(out);
 #pragma unroll
             for (uint32_t half = 0; half < 2u; ++half) {
                 const uint32_t p = half * 64u + lane;                  // pixel within the tile
@@ -508,7 +561,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             }
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (FMT == RD_FMT_RGBA_F16) {
-            rd_u4 *o = reinterpret_cast<rd_u4 *>(out);                 // 2 px = 16 B per lane per row
+            RD_GLOBAL rd_u4 *o = reinterpret_cast<RD_GLOBAL rd_u4 *>(out);   // 2 px = 16 B per lane per row
             rd_u4 va = { r.a0, r.a1, r.a0, r.a1 }, vb = { r.b0, r.b1, r.c0, r.c1 };
             if (!has_a) va = vb;
             if (!has_b) vb = va;
@@ -533,8 +586,8 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             s16[192u + lane * 3u + 2u] = (uint16_t)(pd >> 8);
             __builtin_amdgcn_wave_barrier();
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s16);
-            uint32_t *oa = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + (row_a_px + (size_t)tq * 128u) * 3u);
-            uint32_t *ob = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + (row_b_px + (size_t)tq * 128u) * 3u);
+            RD_GLOBAL uint32_t *oa = reinterpret_cast<RD_GLOBAL uint32_t *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_a_px + (size_t)tq * 128u) * 3u);
+            RD_GLOBAL uint32_t *ob = reinterpret_cast<RD_GLOBAL uint32_t *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_b_px + (size_t)tq * 128u) * 3u);
             const uint32_t a0 = s32[lane], b0 = s32[96u + lane];
             const uint32_t l2 = lane & 31u;
             const uint32_t a1 = s32[64u + l2], b1 = s32[160u + l2];
@@ -546,7 +599,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             }
             __builtin_amdgcn_wave_barrier();
         } else {
-            rd_u2 *o = reinterpret_cast<rd_u2 *>(out);                 // 2 px = 8 B per lane per row
+            RD_GLOBAL rd_u2 *o = reinterpret_cast<RD_GLOBAL rd_u2 *>(out);   // 2 px = 8 B per lane per row
             rd_u2 va = { r.v1, r.v1 }, vb = { r.v2, r.v3 };
             if (!has_a) va = vb;
             if (!has_b) vb = va;
@@ -573,10 +626,12 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
             // Any wave may pull any line (the cache is shared), so the sweep ignores tile ownership.  The
             // count is static (8 x 1 KiB per wave covers 64 MB per launch) so the compiler can still count
             // vmcnt for the tile-0 loads issued above; larger launches finish with a waited loop.
+            // MULTI: the sweep covers frame 0 of the launch; the later frames are swept by prefetch_frame below.
             typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
-            const uint32_t row_lo = unit0 ? 2u * unit0 - 1u : 0u;
-            const uint32_t row_hi = 2u * (unit1 - 1u) < H ? 2u * (unit1 - 1u) + 1u : H;       // exclusive
-            const rd_u4 *src = reinterpret_cast<const rd_u4 *>(cfa + (size_t)row_lo * W);
+            const uint32_t row_lo = MULTI ? 0u : unit0 ? 2u * unit0 - 1u : 0u;
+            const uint32_t row_hi = MULTI ? H : 2u * (unit1 - 1u) < H ? 2u * (unit1 - 1u) + 1u : H;    // exclusive
+            const RD_GLOBAL uint16_t *cfa_b = (const RD_GLOBAL uint16_t *)(MULTI ? descs[0].cfa : cfa_arg);
+            const RD_GLOBAL rd_u4 *src = reinterpret_cast<const RD_GLOBAL rd_u4 *>(cfa_b + (size_t)row_lo * W);
             const size_t n16 = ((size_t)(row_hi - row_lo) * W * sizeof(uint16_t)) / 16u;       // whole 16-B chunks
             const size_t g0 = (size_t)(blockIdx.x * RD_WAVES + wave) * 64u, gstride = (size_t)nwaves * 64u;
             // (host guarantees for BURST launches: cfa 16-byte aligned, W % 128 == 0, at least 1 MB of CFA rows,
@@ -598,11 +653,11 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
                 uint32_t q = qt * 64u + lane;
                 const uint32_t ra = unit ? 2u * unit - 1u : 0u;
                 const uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
-                const uint32_t *pt = reinterpret_cast<const uint32_t *>(cfa + (size_t)ra * W) + q;
-                const uint32_t *pb = reinterpret_cast<const uint32_t *>(cfa + (size_t)rb * W) + q;
+                const RD_GLOBAL uint32_t *pt = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W) + q;
+                const RD_GLOBAL uint32_t *pb = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)rb * W) + q;
                 const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
                     (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&stage[0]) + wave * (192u * 16u));
-                const rd_u4 *a[8];
+                const RD_GLOBAL rd_u4 *a[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     size_t i0 = g0 + (size_t)k * gstride;
@@ -638,33 +693,82 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
         // emits vmcnt(1)/vmcnt(2) there, which on the back edge means "drain the stores in flight".
         asm volatile("" : "+v"(top), "+v"(bot));
 
+        // MULTI + BURST: the read burst of the frames after the first.  There is no chip-wide quiet phase inside a
+        // multi-frame launch, but there is a chip-wide CLOCK: all ticket counters advance together, so every wave
+        // enters frame f within about one tile time of every other.  The wave whose load stage draws its first tile
+        // of frame f issues its share of frame f's sweep -- the same fire-and-forget LDS-DMA as above, 1 KiB per
+        // instruction, into a dump area nobody reads -- so the whole chip requests the plane in one short window and
+        // the frame's remaining loads are served by the Infinity Cache.  hipcc does not count these in its vmcnt
+        // bookkeeping; they retire in order with the tile loads issued just after them, long before the compute
+        // stage that follows has finished.  Measured (tools/bench_batch_ab.py, 8 frames per launch): 79.4 us per
+        // frame with the sweep at frame entry, 84.1 us without any sweep of the later frames; starting the sweep
+        // earlier (pf_thr = 90 ... 99 % of the PREVIOUS frame's tiles) is no better (79.3 ... 80.1), much earlier
+        // (50 ... 75 %) is worse: the sweep then holds back the stores of the tiles in flight.
+        uint32_t pf_next = 1u;                                   // first frame not yet requested by this wave
+        auto prefetch_frame = [&](uint32_t fr) {
+            const char *base = reinterpret_cast<const char *>(descs[fr].cfa);
+            const uint32_t n1k = (uint32_t)(((size_t)H * W * sizeof(uint16_t)) >> 10);   // whole 1-KiB pieces of a plane
+            const uint32_t dump = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&pf_dump[0]));
+            const uint32_t voff = lane * 16u;
+            uint32_t piece = blockIdx.x * RD_WAVES + wave;       // pieces g, g + nwaves, ...: eight cover 64 MB at 8192 waves
+#pragma unroll 1
+            for (int k = 0; k < 8 && piece < n1k; ++k, piece += nwaves) {            // wave-uniform
+                const char *sb = base + ((size_t)piece << 10);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dump), "v"(voff), "s"(sb) : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        };
+
         // Software pipeline, one tile deep on each side:
         //   iteration i:  issue loads(i+1) | store tile i-1 (registers -> LDS transpose -> HBM) | compute tile i
         // vmcnt retires in order, so waiting for loads(i+1) only requires the stores of tile i-2 to
         // have completed; the stores of tile i-1 overlap this wave's own arithmetic.
-        uint32_t ntile = draw();
-        bool more = ntile != ~0u;
         uint32_t nunit = unit, nqt = qt;
-        if (more) split(ntile, nunit, nqt);
+        bool more;
+        auto next_tile = [&]() {                                 // draw, locate, move the load stage into the tile's frame
+            const uint32_t ntile = draw();
+            more = ntile != ~0u;
+            if (more) {
+                uint32_t f, tin;
+                locate(ntile, f, tin, nunit, nqt);
+                if (MULTI) {
+                    if (f != fr_n) { fr_n = f; cfa = (const RD_GLOBAL uint16_t *)descs[f].cfa; }
+                    if (BURST && pf_thr != ~0u) {            // ~0u: later frames are not swept (A/B)
+                        const uint32_t want = f + (tin >= pf_thr ? 1u : 0u);     // newest frame whose window has opened
+                        if (want >= pf_next) {
+                            pf_next = want + 1u;
+                            if (want < nframes) prefetch_frame(want);
+                        }
+                    }
+                }
+            }
+        };
+        next_tile();
         uint32_t ntop, nbot;
         load_tile(nunit, nqt, ntop, nbot);
         rd_tile_out<FMT> pend = compute_tile(unit, qt, top, bot);
         uint32_t punit = unit, pqt = qt;
+        RD_GLOBAL void *out_p = out_c;
         asm volatile("" : "+v"(ntop), "+v"(nbot));               // same reason: nothing pending at the loop header
         while (more) {
 #ifdef RD_PROBE
             ++probe_tiles;
 #endif
             unit = nunit; qt = nqt; top = ntop; bot = nbot;
-            ntile = draw();
-            more = ntile != ~0u;
-            if (more) split(ntile, nunit, nqt);
+            if (MULTI && fr_n != fr_c) {                         // the compute stage enters another frame: its uniforms and surface
+                fr_c = fr_n;
+                out_c = (RD_GLOBAL void *)descs[fr_c].out;
+                adopt(descs[fr_c].u);
+            }
+            next_tile();
             load_tile(nunit, nqt, ntop, nbot);                   // unconditional (the last pass re-reads its own)
-            store_tile(punit, pqt, pend);
+            store_tile(out_p, punit, pqt, pend);
             pend = compute_tile(unit, qt, top, bot);
-            punit = unit; pqt = qt;
+            punit = unit; pqt = qt; out_p = out_c;
         }
-        store_tile(punit, pqt, pend);
+        store_tile(out_p, punit, pqt, pend);
     } else {
         (void)draw();                                            // launch smaller than the grid: still one (failed) draw per wave
     }
@@ -681,6 +785,31 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
         rd_probe_buf[blockIdx.x * 8u + 5u] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
     }
 #endif
+}
+
+// One frame, or one row band of a frame, per launch: rd_render*, the export ring, and rd_batch_develop when the
+// multi-frame launch is switched off (RD_BATCH_PERSISTENT=0).
+template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
+__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
+rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
+                 uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k,
+                 uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
+{
+    rd_quads_body<FMT, HIST, FULL, MATH, BURST, false>(cfa, out, W, H, unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u_arg,
+                                                       slab32, slab64, nullptr, 1u, 0u, 0u, 0u);
+}
+
+// `nframes` whole frames of one size per launch (descs[0 .. nframes-1], frame-major tile index; tpf = tiles per
+// frame): the batch path.  Histogram counts of all frames meet in the workgroup's LDS table (u32: the host keeps
+// nframes * W * H below 2^32) and are added to its u64 slab row at the end of the launch.
+template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
+__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
+rd_develop_batch(const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t W, uint32_t H, uint32_t tpu,
+                 uint32_t tpu_magic, uint32_t tpf, uint32_t tpf_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
+                 uint32_t pf_thr, unsigned long long *slab64)
+{
+    rd_quads_body<FMT, HIST, FULL, MATH, BURST, true>(nullptr, nullptr, W, H, 0u, H / 2u + 1u, tpu, tpu_magic, tq_k, tq_tmax, tq,
+                                                      descs[0].u, nullptr, slab64, descs, nframes, tpf, tpf_magic, pf_thr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
-"""-m gpu: the batch export entry points (rd_batch_*): device-resident frames, one fused launch per
-frame (or per row band), u64 histogram accumulation across frames."""
+"""-m gpu: the batch export entry points (rd_batch_*): device-resident frames, u64 histogram accumulation across
+frames.  Two ways through rd_batch_develop are covered: the default multi-frame launch (one launch covers as many
+frames of the call as the limits allow; tickets, uniforms and surfaces change frame inside the kernel) and, with
+RD_BATCH_PERSISTENT=0, one fused launch per frame or per row band."""
 import numpy as np
 import pytest
 
@@ -54,28 +56,35 @@ def _run_batch(ra, refc, h, w, n, fmt, bands, with_hist=True, math=0):
     be.close()
 
 
+@pytest.fixture(params=["multi_frame", "per_frame"])
+def launch_mode(request, monkeypatch):
+    if request.param == "per_frame":
+        monkeypatch.setenv("RD_BATCH_PERSISTENT", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("fmt_name", ["F32", "F16", "U8"])
 @pytest.mark.parametrize("bands", [1, 3])
-def test_batch_small_frames(gpu_lib, refc, fmt_name, bands):
+def test_batch_small_frames(gpu_lib, refc, fmt_name, bands, launch_mode):
     ra = gpu_lib
     fmt = {"F32": ra.FMT_RGBA_F32, "F16": ra.FMT_RGBA_F16, "U8": ra.FMT_RGBA_U8}[fmt_name]
     _run_batch(ra, refc, 34, 48, 5, fmt, bands)
 
 
-def test_batch_odd_height_many_bands_no_hist(gpu_lib, refc):
+def test_batch_odd_height_many_bands_no_hist(gpu_lib, refc, launch_mode):
     ra = gpu_lib
     _run_batch(ra, refc, 33, 64, 3, ra.FMT_RGBA_F32, 8, with_hist=False)
     _run_batch(ra, refc, 2, 2, 2, ra.FMT_RGBA_F32, 4)          # more bands than units
 
 
-def test_batch_mid_size_frames(gpu_lib, refc):
+def test_batch_mid_size_frames(gpu_lib, refc, launch_mode):
     """A frame big enough to occupy every workgroup of the fixed grid (1504 x 1000)."""
     ra = gpu_lib
     _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F32, 1)
     _run_batch(ra, refc, 1000, 1504, 2, ra.FMT_RGBA_F16, 4)
 
 
-def test_batch_ticket_scheduling(gpu_lib, refc, monkeypatch):
+def test_batch_ticket_scheduling(gpu_lib, refc, monkeypatch, launch_mode):
     """More tiles than resident waves (3008 x 2008: 24 120 tiles against 8192 waves), so most tiles are dealt by the
     ticket counters; repeated launches (the counters must come back to zero), row bands and the optional two-stream
     issue all give the oracle's bits and the same histogram."""
@@ -88,10 +97,45 @@ def test_batch_ticket_scheduling(gpu_lib, refc, monkeypatch):
     monkeypatch.delenv("RD_BATCH_STREAMS")
 
 
-def test_batch_contracted_math(gpu_lib, refc):
+def test_batch_contracted_math(gpu_lib, refc, launch_mode):
     ra = gpu_lib
     _run_batch(ra, refc, 34, 256, 3, ra.FMT_RGBA_F32, 2, math=ra.MATH_CONTRACTED)
     _run_batch(ra, refc, 34, 48, 3, ra.FMT_RGBA_U8, 1, math=ra.MATH_CONTRACTED)
+
+
+def test_multi_frame_launch_limits(gpu_lib, refc, monkeypatch):
+    """The multi-frame path cuts a call into launches: at most RD_BATCH_MAX_FRAMES frames each (diagnostic cap), and
+    never two frames whose surfaces overlap in one launch.  7 frames with caps 1, 2, 3 and 7, then 7 frames written to
+    a ring of 3 surfaces (every launch ends where the ring would wrap): same bits, same histogram."""
+    ra = gpu_lib
+    for cap in ("1", "2", "3", "7"):
+        monkeypatch.setenv("RD_BATCH_MAX_FRAMES", cap)
+        _run_batch(ra, refc, 260, 384, 7, ra.FMT_RGBA_F32, 1)
+    monkeypatch.delenv("RD_BATCH_MAX_FRAMES")
+    # ring of 3: what survives in slot k is the last frame sent there
+    h, w, n, ring = 260, 384, 7, 3
+    rng = np.random.default_rng([0x52415745, 77])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    d_out = [DevBuf(h * w * 4) for _ in range(ring)]
+    d_hist = DevBuf(768 * 8)
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_U8, True)
+    frames = be.make_frames([b.ptr for b in d_in], [d_out[i % ring].ptr for i in range(n)], params, WB_DAYLIGHT, CM_TEST)
+    be.develop(frames)
+    be.histogram(d_hist.ptr)
+    sync()
+    exp_hist = np.zeros(768, np.uint64)
+    exp8 = []
+    for c, p in zip(cfas, params):
+        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+        exp8.append(refc.pack_u8(refc.render_f32(c, u)))
+        exp_hist += refc.histogram(exp8[-1]).reshape(-1).astype(np.uint64)
+    for slot in range(ring):
+        last = max(i for i in range(n) if i % ring == slot)
+        assert np.array_equal(d_out[slot].to_array(np.uint8, (h, w, 4)), exp8[last]), slot
+    assert np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist)
+    be.close()
 
 
 def test_batch_rejects_bad_arguments(gpu_lib):
