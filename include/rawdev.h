@@ -206,6 +206,18 @@ int rd_exporter_submit(rd_exporter *e, const rd_frame *frame, uint32_t *slot);
 int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len);
 int rd_exporter_release(rd_exporter *e, uint32_t slot);
 
+/* ---- self-test ----------------------------------------------------------------------------- */
+/* The RGBA8 / RGB8 surfaces (the reference's target format, pipeline.rs:322) compute their 8-bit codes with a shortcut
+ * (hardware log2/exp2, the pinned evaluation only near a code boundary).  rd_selftest_q8 runs that
+ * shortcut and the pinned trunc(255 * gamma(x) + 0.5) over ALL 2^32 float encodings on `device` (about a second) and
+ * reports how many differ (must be 0; *first_bad = the smallest differing encoding or 0xffffffff), how many encodings
+ * take the pinned evaluation, and the largest distance in codes between the two evaluations before truncation.
+ * Any output pointer may be NULL. */
+int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks, float *max_dist);
+/* The shortcut's codes for the float encodings first_encoding .. first_encoding + n - 1 (n a multiple of 256), so a
+ * host-side oracle can be compared with them. */
+int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst);
+
 /* ---- plumbing for hosts without a HIP binding (tests, the Python mirror) -------------------- */
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "rd_exporter_submit": (_I, [_VP, C.POINTER(RdFrame), C.POINTER(_U32)]),
     "rd_exporter_wait": (_I, [_VP, _U32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rd_exporter_release": (_I, [_VP, _U32]),
+    "rd_selftest_q8": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+    "rd_selftest_q8_codes": (_I, [_I, _U32, _U32, _VP]),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_device_free": (_I, [_I, _VP]),
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),
@@ -112,11 +114,12 @@ def lib():
     """Load librawdev.so (once).  Raises if it has not been built: there is no fallback."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RawdevError(-5, f"{LIB_PATH} is missing: run `python -m raweditor_amd.build` "
+        path = os.environ.get("RAWDEV_LIB") or LIB_PATH          # RAWDEV_LIB: an A/B build of the same ABI (tools/)
+        if not os.path.exists(path):
+            raise RawdevError(-5, f"{path} is missing: run `python -m raweditor_amd.build` "
                                   "(hipcc --offload-arch=gfx950); librawdev has no CPU fallback")
         _preload_hip_runtime()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError if the .so does not export it
             fn.restype = res

@@ -958,6 +958,70 @@ extern "C" int rd_exporter_release(rd_exporter *e, uint32_t slot)
 }
 
 // ------------------------------------------------------------------------------------------------
+// self-test of the 8-bit surfaces' gamma shortcut (rd_kernels.h, rd_q8_gamma) over every float encoding
+// ------------------------------------------------------------------------------------------------
+struct rd_q8_stats { unsigned long long mismatches, fallbacks; uint32_t first_bad, max_dist_bits; };
+
+__global__ void __launch_bounds__(256) rd_q8_sweep(uint32_t base, rd_q8_stats *st, uint8_t *codes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = rd_u2f(base + i);
+    const uint32_t fast = rd_q8_gamma(x);
+    const uint32_t exact = rd_q8(rd_gamma_clamp(x));
+    if (codes) codes[i] = (uint8_t)fast;
+    if (!st) return;
+    if (fast != exact || fast > 255u) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
+    if (x >= RD_FLT_MIN) {
+        float y = __builtin_fmaf(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * RD_INV_GAMMA), 255.0f, 0.5f);
+        y = __builtin_fminf(y, 255.5f);
+        const float d = __builtin_fabsf(y - (rd_gamma_clamp(x) * 255.0f + 0.5f));
+        if (__builtin_fabsf(__builtin_amdgcn_fractf(y) - 0.5f) > 0.5f - RD_Q8_EPS) atomicAdd(&st->fallbacks, 1ull);
+        atomicMax(&st->max_dist_bits, rd_f2u(d));               // d >= 0: integer order == float order
+    }
+}
+
+extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks, float *max_dist)
+{
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
+    RD_HIP(hipMalloc((void **)&dst, sizeof st));
+    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
+    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {    // 256 launches x 2^24 encodings
+        hipLaunchKernelGGL(rd_q8_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint8_t *)nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8: %s", hipGetErrorString(e));
+    if (mismatches) *mismatches = st.mismatches;
+    if (first_bad) *first_bad = st.first_bad;
+    if (fallbacks) *fallbacks = st.fallbacks;
+    if (max_dist) *max_dist = rd_u2f(st.max_dist_bits);
+    return RD_OK;
+}
+
+extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
+{
+    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
+        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_q8_codes: n must be a non-zero multiple of 256 inside the 2^32 encodings");
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    uint8_t *dev = nullptr;
+    RD_HIP(hipMalloc((void **)&dev, n));
+    hipLaunchKernelGGL(rd_q8_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(dst, dev, n, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_codes: %s", hipGetErrorString(e));
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // plumbing
 // ------------------------------------------------------------------------------------------------
 extern "C" int rd_device_malloc(int device, size_t bytes, void **out)

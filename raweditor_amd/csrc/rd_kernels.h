@@ -69,7 +69,9 @@ __device__ __forceinline__ float rd_dot709_c(float r, float g, float b)      // 
 // (rd_uniforms.h) marks as an exact identity for this frame's uniforms is skipped behind ONE wave-uniform branch for all N.  With all sliders away
 // from their defaults nothing is skipped; a typical edit (identity matrix -- the reference never passes another one --
 // and a few untouched sliders) sheds a quarter of the linear part.  Results are written back into r, g, b.
-template <int N, int MATH>
+// GAMMA = false stops before the gamma / clamp step (:261-264) and returns the linear values: the 8-bit surfaces finish
+// with rd_q8_gamma below.
+template <int N, int MATH, bool GAMMA = true>
 __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
 {
     constexpr bool C = MATH == RD_MATH_CONTRACTED;
@@ -192,8 +194,10 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
             }
         }
     }
+    if constexpr (GAMMA) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) { r[i] = rd_gamma_clamp(r[i]); g[i] = rd_gamma_clamp(g[i]); b[i] = rd_gamma_clamp(b[i]); }   // :261-264
+        for (int i = 0; i < N; ++i) { r[i] = rd_gamma_clamp(r[i]); g[i] = rd_gamma_clamp(g[i]); b[i] = rd_gamma_clamp(b[i]); }   // :261-264
+    }
 }
 
 template <int MATH>
@@ -213,6 +217,31 @@ __device__ __forceinline__ float rd_norm(uint32_t raw, uint32_t bl)
 
 // Rgba8Unorm quantisation (pipeline.rs:322), pinned as trunc(x*255 + 0.5).
 __device__ __forceinline__ uint32_t rd_q8(float x) { return (uint32_t)(x * 255.0f + 0.5f); }
+
+// rd_q8(rd_gamma_clamp(x)) for the surfaces that keep only the 8-bit code (RGBA8 -- the reference's own target format,
+// pipeline.rs:322 -- and RGB8), in a third of the instructions.  The code is a step function of x with 255 steps; between
+// two steps ANY evaluation of pow(x, 1/2.2) that is accurate to a small fraction of a code gives the same answer.  So:
+// the hardware's v_log_f32 / v_exp_f32 (about 1 ULP each; the lowering the reference's Vulkan drivers use, rd_math.h)
+// give y' = 255 * 2^(log2(x) / 2.2) + 0.5, whose distance from the pinned y is below RD_Q8_EPS codes for every float
+// (tools/q8_exhaustive.hip measures the largest distance over all 2^32 encodings), and only a lane whose y' lies within
+// RD_Q8_EPS of an integer -- where the two could fall on different sides of a step -- takes the pinned evaluation
+// (about one lane in 2000; the branch is skipped when no lane of the wave needs it).  Measured largest distance:
+// 3.05e-5 codes (profiles/r02_q8_exhaustive.txt); RD_Q8_EPS keeps 8x that.  Every float encoding is checked
+// against rd_q8(rd_gamma_clamp(x)) on the device and against the oracle's pow + clamp + pack on the host by
+// tools/q8_exhaustive.hip (tests/test_gpu_q8.py runs the device half in the -m gpu suite).
+#ifndef RD_Q8_EPS
+#define RD_Q8_EPS 0.00025f
+#endif
+__device__ __forceinline__ uint32_t rd_q8_gamma(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * RD_INV_GAMMA);
+    float y = __builtin_fmaf(e, 255.0f, 0.5f);
+    y = __builtin_fminf(y, 255.5f);                              // x >= 1 and +inf: code 255
+    uint32_t q = (uint32_t)y;
+    const float f = __builtin_amdgcn_fractf(y) - 0.5f;
+    if (__builtin_fabsf(f) > 0.5f - RD_Q8_EPS) q = rd_q8(rd_gamma_clamp(x));
+    return x >= RD_FLT_MIN ? q : 0u;                             // negative, NaN, zero, subnormal: code 0 (rd_gamma_clamp's cases)
+}
 
 // ---------------------------------------------------------------------------------------------
 // Histogram: RD_HK private copies of every bin in LDS, copy = lane % RD_HK, so a flat frame (all 64
@@ -490,11 +519,23 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         const rd_rgb c2 = RD_COLOUR(u, C, D, A);
         const rd_rgb c3 = RD_COLOUR(u, C, D, B);
 #else
+#ifdef RD_NO_Q8_SHORTCUT   // A/B builds only (tools/): the 8-bit surfaces go through the pinned gamma like the others
+        constexpr bool Q8ONLY = false;
+#else
+        constexpr bool Q8ONLY = FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8;    // only the 8-bit codes leave the kernel
+#endif
         float tr[3] = { C, C, C }, tg[3] = { A, D, D }, tb[3] = { B, A, B };       // row a: (C,A,B); row b: (C,D,A), (C,D,B)
-        rd_colour_n<3, MATH>(u, tr, tg, tb);
+        rd_colour_n<3, MATH, !Q8ONLY>(u, tr, tg, tb);
         const rd_rgb c1 = { tr[0], tg[0], tb[0] }, c2 = { tr[1], tg[1], tb[1] }, c3 = { tr[2], tg[2], tb[2] };
 #endif
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
+#ifndef RD_COLOUR_HOOK_HEADER
+        if constexpr (Q8ONLY) {
+            q1r = rd_q8_gamma(c1.r); q1g = rd_q8_gamma(c1.g); q1b = rd_q8_gamma(c1.b);
+            q2r = rd_q8_gamma(c2.r); q2g = rd_q8_gamma(c2.g); q2b = rd_q8_gamma(c2.b);
+            q3r = rd_q8_gamma(c3.r); q3g = rd_q8_gamma(c3.g); q3b = rd_q8_gamma(c3.b);
+        } else
+#endif
         if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
             q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
@@ -830,6 +871,7 @@ __global__ void __launch_bounds__(RD_BLOCK)
 rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                uint32_t tw, uint32_t th, rd_ku u, uint32_t *slab32, unsigned long long *slab64)
 {
+    constexpr bool Q8ONLY = FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8;
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     if (HIST) rd_hist_zero(lh);
     const uint32_t copy = threadIdx.x & (RD_HK - 1);
@@ -858,10 +900,17 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
                 if (even_col) { r = n; g = rd_tap(cfa, W, H, px + 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
                 else          { g = n; r = rd_tap(cfa, W, H, px - 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
             }
-            c = rd_colour_m<MATH>(u, r, g, b);
+            if constexpr (Q8ONLY) {                    // linear values; rd_q8_gamma finishes (out-of-bounds pixels stay 0 -> code 0)
+                float tr[1] = { r }, tg[1] = { g }, tb[1] = { b };
+                rd_colour_n<1, MATH, false>(u, tr, tg, tb);
+                c = rd_rgb{ tr[0], tg[0], tb[0] };
+            } else {
+                c = rd_colour_m<MATH>(u, r, g, b);
+            }
         }
         uint32_t qr = 0, qg = 0, qb = 0;
-        if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }
+        if constexpr (Q8ONLY) { qr = rd_q8_gamma(c.r); qg = rd_q8_gamma(c.g); qb = rd_q8_gamma(c.b); }
+        else if (HIST) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }
         rd_store_px<FMT>(out, idx, c, qr, qg, qb);
         if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 1u);
     }

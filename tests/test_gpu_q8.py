@@ -1,0 +1,75 @@
+"""-m gpu: the 8-bit surfaces' gamma shortcut (rd_kernels.h::rd_q8_gamma) is the pinned function, code for code.
+
+  * on the device, for ALL 2^32 float encodings: rd_q8_gamma(x) == trunc(255 * rd_gamma_clamp(x) + 0.5) (rd_selftest_q8);
+  * against the ORACLE (ref_powf -> clamp -> ref_pack_u8): every encoding in a window around each of the 255 code
+    steps, the special encodings, and a stride through all 2^32 (tools/q8_exhaustive.hip does every encoding against the
+    oracle; its output is kept in profiles/).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(ra, first, n):
+    from raweditor_amd import _lib
+    out = np.empty(n, np.uint8)
+    _lib.check(_lib.lib().rd_selftest_q8_codes(0, first, n, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def _oracle_codes(refc, bits):
+    L = refc.lib()
+    x = bits.astype(np.uint32).view(np.float32)
+    g = np.empty_like(x)
+    for i, v in enumerate(x):                        # scalar ref_powf through ctypes: keep the samples modest
+        g[i] = L.ref_powf(C.c_float(v), C.c_float(np.float32(0.45454547)), 0)
+    g = np.where(g > 0, g, np.float32(0)).astype(np.float32)      # max(c, 0), NaN -> 0
+    g = np.minimum(g, np.float32(1))
+    return refc.pack_u8(g)
+
+
+def test_q8_shortcut_equals_the_pinned_codes_for_every_float(gpu_lib):
+    from raweditor_amd import _lib
+    bad, first, fb, dist = C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_float()
+    _lib.check(_lib.lib().rd_selftest_q8(0, C.byref(bad), C.byref(first), C.byref(fb), C.byref(dist)))
+    assert bad.value == 0, f"{bad.value} encodings differ, first 0x{first.value:08x}"
+    assert dist.value * 4 < 0.00025, dist.value      # RD_Q8_EPS = 2.5e-4: at least 4x the largest distance seen here
+    assert 0 < fb.value < 2**31 * 0.01               # the pinned evaluation is the rare path
+
+
+def test_q8_shortcut_against_the_oracle(gpu_lib, refc):
+    ra = gpu_lib
+    # where the oracle's code changes: bisect each of the 255 steps over the non-negative encodings
+    L = refc.lib()
+
+    def oracle_code(bits):
+        return int(_oracle_codes(refc, np.array([bits], np.uint32))[0])
+
+    assert oracle_code(0) == 0 and oracle_code(0x3f800000) == 255
+    checked = 0
+    for k in range(1, 256):
+        lo, hi = 0, 0x3f800000                       # code(lo) < k <= code(hi)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if oracle_code(mid) >= k:
+                hi = mid
+            else:
+                lo = mid
+        first = (max(hi - 512, 0) // 256) * 256
+        bits = np.arange(first, first + 1024, dtype=np.uint32)
+        assert np.array_equal(_codes(ra, first, 1024), _oracle_codes(refc, bits)), f"step to code {k} near 0x{hi:08x}"
+        checked += 1024
+    # specials and a stride through every exponent, both signs
+    for first in (0x00000000, 0x007fff00, 0x00800000, 0x3f7fff00, 0x3f800000, 0x7f7fff00, 0x7f800000, 0x7fc00000,
+                  0x80000000, 0xbf800000, 0xff800000, 0xffffff00):
+        bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
+        assert np.array_equal(_codes(ra, first, 256), _oracle_codes(refc, bits)), hex(first)
+    rng = np.random.default_rng(8)
+    for first in rng.integers(0, 2**32 - 256, 64, dtype=np.uint64):
+        first = int(first) // 256 * 256
+        bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
+        assert np.array_equal(_codes(ra, first, 256), _oracle_codes(refc, bits)), hex(first)
+    assert checked == 255 * 1024
