@@ -259,6 +259,12 @@ def main():
     except (OSError, ValueError):
         pass
 
+    if (W, H) == (6016, 4016):
+        cfg_label = "BASELINE configs[2]" if world == 1 else "BASELINE configs[3] (256 frames per GPU)"
+    elif (W, H) == (11648, 8736):
+        cfg_label = "BASELINE configs[4] shape (100 MP; per GPU)"
+    else:
+        cfg_label = "custom frame size"
     result = {
         "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
         "value": round(total_px / 1e6 / elapsed, 1),
@@ -275,7 +281,7 @@ def main():
         "verified": verified,
         "verified_note": verified_note,
         "config": {
-            "workload": f"BASELINE configs[2]: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
+            "workload": f"{cfg_label}: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
                         f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}, "
                         f"{args.math} f32 arithmetic",
             "frames_per_gpu": F, "width": W, "height": H, "surface": f"rgba_{args.format}",
