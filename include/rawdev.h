@@ -188,6 +188,30 @@ uint32_t rd_batch_last_launch_count(const rd_batch *b);
  * and reset the accumulator.  Enqueued on `stream`; the multi-GPU sum is the caller's all-reduce. */
 int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);
 
+/* ---- node-level batch (SURVEY.md section 8b "Batch", 8e; BASELINE.json configs[3]) ----------------------- */
+/* The batch path over the GPUs of one node from ONE process -- what a Rust or C host calls; bench.py and the Python
+ * mirror reach the same sharding with one process per GPU and torch.distributed (raweditor_amd/batch.py).
+ * Frame i of a call belongs to devices[i mod n_devices]; its cfa_dev / out_dev must live in THAT device's HBM
+ * (rd_device_malloc(device, ...)).  No pixel crosses xGMI.  One rd_batch, one stream and one host thread per device.
+ * The only exchange is the global histogram: ncclAllReduce(768, ncclUint64, ncclSum) over RCCL (librccl.so is loaded on
+ * first use, and only when n_devices > 1); with one device there is no communicator.
+ * Environment: RD_NODE_REDUCE=host folds the per-device histograms on the host instead (and then accepts a device
+ * listed twice: a rehearsal of N > 1 on a one-GPU box); RD_NODE_REDUCE=rccl builds a communicator even for one device;
+ * RAWDEV_RCCL_LIB names the library file. */
+typedef struct rd_node_batch rd_node_batch;
+int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
+                         uint32_t with_histogram, rd_node_batch **out);
+void rd_node_batch_destroy(rd_node_batch *nb);
+int rd_node_batch_set_math_mode(rd_node_batch *nb, uint32_t math_mode);
+/* The dealing rule, for hosts that place their buffers: index into devices[] that owns frame `frame_index`. */
+uint32_t rd_node_batch_device_of(uint32_t n_devices, size_t frame_index);
+/* Enqueue all frames (each device's share through rd_batch_develop on that device's stream).  Not synchronised. */
+int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_frames, uint32_t row_bands);
+/* Global histogram of everything developed since the last call: per-device fold, all-reduce, copy to `hist`
+ * (R[256] G[256] B[256], u64).  Returns when every device has finished; resets the accumulators. */
+int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768]);
+int rd_node_batch_synchronize(rd_node_batch *nb);
+
 /* ---- export feed (the step after the path) ----------------------------------- */
 /* The GPU half of export_image_async (main.rs:1744-1799) for a stream of frames: render_full_res_to_bytes'
  * blocking map/copy (pipeline.rs:552-605, "1-2 s for 24 MP") becomes a ring of pinned host buffers filled by

@@ -36,6 +36,49 @@ def allreduce_histogram(hist64):
     return hist64
 
 
+class NodeBatch:
+    """rd_node_batch: the batch path over several GPUs of one node from ONE process (what a Rust / C host uses).
+    Frame i belongs to devices[i mod N]; the global histogram is one RCCL all-reduce of 768 x u64."""
+
+    def __init__(self, devices: Sequence[int], width: int, height: int, fmt: int, with_histogram: bool = True,
+                 math_mode: int = _lib.MATH_STRICT):
+        self._h = C.c_void_p()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        check(_lib.lib().rd_node_batch_create(arr, len(self.devices), int(width), int(height), int(fmt),
+                                              1 if with_histogram else 0, C.byref(self._h)))
+        if math_mode != _lib.MATH_STRICT:
+            check(_lib.lib().rd_node_batch_set_math_mode(self._h, int(math_mode)))
+
+    def device_of(self, frame_index: int) -> int:
+        """The device (not the index into `devices`) that owns frame `frame_index`."""
+        return self.devices[_lib.lib().rd_node_batch_device_of(len(self.devices), int(frame_index))]
+
+    def develop(self, frames, row_bands: int = 1) -> None:
+        check(_lib.lib().rd_node_batch_develop(self._h, frames, len(frames), int(row_bands)))
+
+    def histogram(self):
+        """Global (3, 256) uint64 histogram of everything developed since the last call; synchronises."""
+        import numpy as np
+        out = np.zeros(768, np.uint64)
+        check(_lib.lib().rd_node_batch_histogram(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(3, 256)
+
+    def synchronize(self) -> None:
+        check(_lib.lib().rd_node_batch_synchronize(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().rd_node_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BatchExporter:
     """rd_batch: fused demosaic+develop(+histogram) launches for same-sized frames on one device."""
 

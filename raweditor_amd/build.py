@@ -22,7 +22,7 @@ HEADERS = ["rd_math.h", "rd_uniforms.h", "rd_kernels.h", os.path.join("..", ".."
 # operand pair that happens to contain a pending load's register makes hipcc drain the store queue mid-loop (false
 # vmcnt dependency); scalar f32 code keeps the s_waitcnt placement exact.
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-               "-std=c++17", "-Wall", "-Wextra", "-Rpass-analysis=kernel-resource-usage"]
+               "-std=c++17", "-Wall", "-Wextra", "-Rpass-analysis=kernel-resource-usage", "-pthread", "-ldl"]
 RESOURCES_PATH = os.path.join(PKG_DIR, "kernel_resources.json")
 # The export kernel runs two 1024-thread workgroups per CU (8 waves per SIMD).  That holds only while a wave needs
 # <= 64 VGPRs and <= 80 SGPRs (the kernel carries amdgpu_num_sgpr(80), so the compiler spills rather than exceed it)

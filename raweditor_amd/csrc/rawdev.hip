@@ -11,6 +11,8 @@
 // There is no CPU compute path in this file: every render is a gfx950 kernel launch.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,8 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rawdev.h"
@@ -819,6 +823,219 @@ extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
                        b->blocks * b->n_streams, (unsigned long long *)hist_dev);
     RD_HIP(hipGetLastError());
     return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_node_batch: the batch path over the GPUs of one node from ONE process (SURVEY.md section 8b "Batch", 8e)
+//
+// Frames share nothing (the demosaic clamps at the frame edge, shaders.rs:163-166), so frame i simply belongs to device
+// i mod N; its CFA plane and surface live in that device's HBM and no pixel crosses xGMI.  One rd_batch, one stream and
+// one 768 x u64 histogram per device; enqueueing is done by one host thread per device.  The only exchange is the global
+// histogram: ncclAllReduce(768, ncclUint64, ncclSum) over RCCL (librccl.so is loaded on first use and only when N > 1;
+// u64 because 2048 x 24 MP overflows u32).  With N = 1 there is no communicator.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct rd_rccl_api {
+    void *handle = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+    bool ok = false;
+};
+constexpr int RD_NCCL_UINT64 = 5, RD_NCCL_SUM = 0;           // rccl.h: ncclUint64, ncclSum
+
+rd_rccl_api &rd_rccl()
+{
+    static rd_rccl_api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = getenv("RAWDEV_RCCL_LIB");
+        const char *names[] = { env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        // a copy that is already mapped (a PyTorch process has its own) serves us too: one RCCL per process
+        for (const char *n : { "librccl.so.1", "librccl.so" })
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names)
+            if (!api.handle && n && *n) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) { api.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(api.handle, n); if (!p && api.error.empty()) api.error = std::string("librccl.so lacks ") + n; return p; };
+        api.CommInitAll = (int (*)(void **, int, const int *))sym("ncclCommInitAll");
+        api.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+        api.GroupStart = (int (*)())sym("ncclGroupStart");
+        api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+        api.ok = api.error.empty();
+    });
+    return api;
+}
+}  // namespace
+
+enum { RD_NODE_REDUCE_NONE = 0, RD_NODE_REDUCE_RCCL = 1, RD_NODE_REDUCE_HOST = 2 };
+
+struct rd_node_batch {
+    uint32_t n = 0, w = 0, h = 0, fmt = 0;
+    bool hist = false;
+    int reduce = RD_NODE_REDUCE_NONE;
+    std::vector<int> devices;
+    std::vector<rd_batch *> batches;
+    std::vector<hipStream_t> streams;
+    std::vector<uint64_t *> hist_dev;          // 768 x u64 per device
+    std::vector<void *> comms;                 // ncclComm_t per device (RCCL only)
+    std::vector<std::vector<rd_frame>> share;  // the frames of the current call, per device
+};
+
+extern "C" uint32_t rd_node_batch_device_of(uint32_t n_devices, size_t frame_index)
+{
+    return n_devices ? (uint32_t)(frame_index % n_devices) : 0u;      // frame i -> GPU i mod N
+}
+
+extern "C" void rd_node_batch_destroy(rd_node_batch *nb)
+{
+    if (!nb) return;
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        rd_devguard g(nb->devices[d]);
+        if (d < nb->streams.size() && nb->streams[d]) (void)hipStreamSynchronize(nb->streams[d]);
+    }
+    if (nb->reduce == RD_NODE_REDUCE_RCCL && rd_rccl().ok)
+        for (void *c : nb->comms) if (c) (void)rd_rccl().CommDestroy(c);
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        if (d < nb->batches.size()) rd_batch_destroy(nb->batches[d]);
+        rd_devguard g(nb->devices[d]);
+        if (d < nb->hist_dev.size() && nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
+        if (d < nb->streams.size() && nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
+    }
+    delete nb;
+}
+
+extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
+                                    uint32_t with_histogram, rd_node_batch **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!devices || !n_devices || n_devices > 64) return rd_fail(RD_ERR_INVALID_ARG, "need 1..64 devices");
+    bool dup = false;
+    for (uint32_t a = 0; a < n_devices; ++a)
+        for (uint32_t b = a + 1; b < n_devices; ++b) dup = dup || devices[a] == devices[b];
+    const char *env = getenv("RD_NODE_REDUCE");              // "host": fold on the host; "rccl": a communicator even for N = 1
+    const bool want_host = env && !strcmp(env, "host"), want_rccl = env && !strcmp(env, "rccl");
+    if (dup && !want_host)
+        return rd_fail(RD_ERR_INVALID_ARG, "device list holds a device twice (RCCL wants one rank per device; RD_NODE_REDUCE=host "
+                                           "allows it for rehearsals on a one-GPU box)");
+    rd_node_batch *nb = new (std::nothrow) rd_node_batch;
+    if (!nb) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    nb->n = n_devices; nb->w = width; nb->h = height; nb->fmt = format; nb->hist = with_histogram != 0;
+    nb->devices.assign(devices, devices + n_devices);
+    nb->batches.assign(n_devices, nullptr);
+    nb->streams.assign(n_devices, nullptr);
+    nb->hist_dev.assign(n_devices, nullptr);
+    nb->comms.assign(n_devices, nullptr);
+    nb->share.resize(n_devices);
+    int rc = RD_OK;
+    for (uint32_t d = 0; d < n_devices && rc == RD_OK; ++d) {
+        rc = rd_batch_create(devices[d], width, height, format, with_histogram, &nb->batches[d]);
+        if (rc) break;
+        rd_devguard g(devices[d]);
+        hipError_t e = hipStreamCreateWithFlags(&nb->streams[d], hipStreamNonBlocking);
+        if (e == hipSuccess && nb->hist) e = hipMalloc((void **)&nb->hist_dev[d], 768 * sizeof(uint64_t));
+        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "device %d: %s", devices[d], hipGetErrorString(e));
+    }
+    if (rc == RD_OK && nb->hist) {
+        if (want_host) nb->reduce = n_devices > 1 ? RD_NODE_REDUCE_HOST : RD_NODE_REDUCE_NONE;
+        else if (n_devices > 1 || want_rccl) {
+            rd_rccl_api &api = rd_rccl();
+            if (!api.ok) rc = rd_fail(RD_ERR_UNSUPPORTED, "global histogram over %u devices needs RCCL: %s", n_devices, api.error.c_str());
+            else {
+                const int r = api.CommInitAll(nb->comms.data(), (int)n_devices, nb->devices.data());
+                if (r != 0) rc = rd_fail(RD_ERR_HIP, "ncclCommInitAll: %s", api.GetErrorString(r));
+                else nb->reduce = RD_NODE_REDUCE_RCCL;
+            }
+        }
+    }
+    if (rc) { std::string keep = g_err; rd_node_batch_destroy(nb); snprintf(g_err, sizeof g_err, "%s", keep.c_str()); return rc; }
+    *out = nb;
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_set_math_mode(rd_node_batch *nb, uint32_t mode)
+{
+    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
+    for (rd_batch *b : nb->batches) { int rc = rd_batch_set_math_mode(b, mode); if (rc) return rc; }
+    return RD_OK;
+}
+
+// run fn(d) for every device, on one host thread per device when there is more than one; first error wins
+template <typename F> static int rd_node_for_each(rd_node_batch *nb, F fn)
+{
+    if (nb->n == 1) return fn(0u);
+    std::vector<int> rcs(nb->n, RD_OK);
+    std::vector<std::string> msgs(nb->n);
+    std::vector<std::thread> th;
+    th.reserve(nb->n);
+    for (uint32_t d = 0; d < nb->n; ++d)
+        th.emplace_back([&, d] { rcs[d] = fn(d); if (rcs[d]) msgs[d] = rd_last_error(); });
+    for (auto &t : th) t.join();
+    for (uint32_t d = 0; d < nb->n; ++d)
+        if (rcs[d]) return rd_fail(rcs[d], "device %d: %s", nb->devices[d], msgs[d].c_str());
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_frames, uint32_t row_bands)
+{
+    if (!nb || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    for (auto &v : nb->share) v.clear();
+    for (size_t i = 0; i < n_frames; ++i) nb->share[rd_node_batch_device_of(nb->n, i)].push_back(frames[i]);
+    return rd_node_for_each(nb, [&](uint32_t d) -> int {
+        const std::vector<rd_frame> &v = nb->share[d];
+        return v.empty() ? (int)RD_OK : rd_batch_develop(nb->batches[d], v.data(), v.size(), row_bands, nb->streams[d]);
+    });
+}
+
+extern "C" int rd_node_batch_synchronize(rd_node_batch *nb)
+{
+    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        rd_devguard g(nb->devices[d]);
+        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
+        RD_HIP(hipStreamSynchronize(nb->streams[d]));
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768])
+{
+    if (!nb || !hist) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
+    // per-device fold of the slabs into 768 x u64, on each device's stream (after the launches enqueued there)
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        int rc = rd_batch_histogram(nb->batches[d], nb->hist_dev[d], nb->streams[d]);
+        if (rc) return rc;
+    }
+    if (nb->reduce == RD_NODE_REDUCE_RCCL) {                  // one in-place all-reduce of 6 KiB per device, grouped
+        rd_rccl_api &api = rd_rccl();
+        int r = api.GroupStart();
+        for (uint32_t d = 0; d < nb->n && r == 0; ++d) {
+            rd_devguard g(nb->devices[d]);
+            r = api.AllReduce(nb->hist_dev[d], nb->hist_dev[d], 768, RD_NCCL_UINT64, RD_NCCL_SUM, nb->comms[d], nb->streams[d]);
+        }
+        const int r2 = api.GroupEnd();
+        if (r == 0) r = r2;
+        if (r != 0) return rd_fail(RD_ERR_HIP, "ncclAllReduce: %s", api.GetErrorString(r));
+    }
+    const uint32_t take = nb->reduce == RD_NODE_REDUCE_HOST ? nb->n : 1u;      // after an all-reduce every device holds the sum
+    uint64_t part[768];
+    memset(hist, 0, 768 * sizeof(uint64_t));
+    for (uint32_t d = 0; d < take; ++d) {
+        rd_devguard g(nb->devices[d]);
+        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
+        RD_HIP(hipMemcpyAsync(part, nb->hist_dev[d], sizeof part, hipMemcpyDeviceToHost, nb->streams[d]));
+        RD_HIP(hipStreamSynchronize(nb->streams[d]));
+        for (int k = 0; k < 768; ++k) hist[k] += part[k];
+    }
+    return rd_node_batch_synchronize(nb);                      // the call returns with every device's work done
 }
 
 // ------------------------------------------------------------------------------------------------

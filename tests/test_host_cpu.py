@@ -202,3 +202,25 @@ def test_elided_steps_flags():
         assert not tiny & (FIX | SAT | VIB) and tiny & MAT
         nan = ra.elided_steps(ra.EditParams(highlights=float("nan")), wb, ident, math)
         assert not nan & HL
+
+
+def test_node_batch_dealing_rule_and_no_device():
+    """rd_node_batch_* (SURVEY.md section 8b "Batch" / 8e): frame i -> devices[i mod N] for N = 1, 2, 4, 8, the same rule
+    raweditor_amd.batch.shard_frames uses for one-process-per-GPU runs; and without a device the node entry fails loudly."""
+    import ctypes as C
+    from raweditor_amd.batch import shard_frames
+    L = _lib.lib()
+    for n in (1, 2, 4, 8):
+        owners = [L.rd_node_batch_device_of(n, i) for i in range(2048)]
+        assert owners == [i % n for i in range(2048)]
+        for r in range(n):
+            assert [i for i, o in enumerate(owners) if o == r] == shard_frames(2048, r, n)
+        assert max(owners.count(r) for r in range(n)) - min(owners.count(r) for r in range(n)) == 0   # 2048 = 8 x 256 even
+    assert L.rd_node_batch_device_of(0, 5) == 0
+    import raweditor_amd as ra
+    if ra.device_count() == 0:
+        h = C.c_void_p()
+        devs = (C.c_int * 2)(0, 1)
+        rc = L.rd_node_batch_create(devs, 2, 64, 64, ra.FMT_RGBA_F32, 1, C.byref(h))
+        assert rc in (-2, -3) and not h.value, (rc, L.rd_last_error())
+        assert L.rd_node_batch_develop(None, None, 0, 1) == -1
