@@ -146,10 +146,10 @@ int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format, v
               size_t dst_len, uint32_t hist[768]);
 /* Device-resident variant: `dst_dev` (and nullable `hist_dev`, 768 x u32) are device pointers on
  * the pipeline's device; work is enqueued on `stream` (a hipStream_t, NULL = default stream) and
- * NOT synchronised.  The fused histogram uses scratch owned by the pipeline: renders WITH a histogram on one
- * pipeline must be enqueued on one stream at a time (renders without one may overlap freely).  The first
- * full-resolution render on a stream allocates that stream's 32 KiB of tile-scheduler state (synchronous; do it before
- * capturing the stream into a graph). */
+ * NOT synchronised.  Renders on different streams may overlap freely, with or without a histogram: the pipeline keeps
+ * its tile-scheduler counters and its histogram slab per stream (at most 16 streams at a time; beyond that the least
+ * recently used stream's state is reused once its work has finished).  The first full-resolution render on a stream
+ * allocates that state (synchronous; do it before capturing the stream into a graph). */
 int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format,
                      void *dst_dev, uint32_t *hist_dev, void *stream);
 
@@ -248,6 +248,16 @@ int rd_device_free(int device, void *ptr);
 int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes);
 int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t bytes);
 int rd_device_synchronize(int device);
+int rd_stream_create(int device, void **stream_out);   /* a non-blocking hipStream_t on `device` */
+int rd_stream_synchronize(int device, void *stream);
+int rd_stream_destroy(int device, void *stream);
+
+/* ---- test hooks (the -m gpu suite; a host never needs them) -------------------------------- */
+/* Overwrites the tile-scheduler counters this pipeline keeps for `stream` (NULL = its own stream) with garbage and marks
+ * them suspect, as the library does itself when a launch or a synchronisation on that stream fails; the next render on
+ * the stream must re-zero them and come out right. */
+int rd_debug_poison_scheduler(rd_pipeline *p, void *stream);
+uint32_t rd_debug_scheduler_entries(rd_pipeline *p);   /* streams this pipeline currently keeps state for (<= 16) */
 
 #ifdef __cplusplus
 }

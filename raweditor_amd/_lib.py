@@ -94,6 +94,11 @@ PROTOTYPES = {
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),
     "rd_memcpy_d2h": (_I, [_I, _VP, _VP, _SZ]),
     "rd_device_synchronize": (_I, [_I]),
+    "rd_stream_create": (_I, [_I, C.POINTER(_VP)]),
+    "rd_stream_synchronize": (_I, [_I, _VP]),
+    "rd_stream_destroy": (_I, [_I, _VP]),
+    "rd_debug_poison_scheduler": (_I, [_VP, _VP]),
+    "rd_debug_scheduler_entries": (_U32, [_VP]),
 }
 
 _lib = None

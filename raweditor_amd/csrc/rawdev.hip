@@ -154,29 +154,100 @@ struct rd_launch_cfg {
     uint32_t wg_per_cu_plain = 2;    // 2 x 1024 threads = the CU's 32 waves
 };
 
-// Ticket counters of the export kernel (rd_kernels.h, "Scheduling"): up to RD_MAX_BLOCKS / 4 counters, one per 128-byte
-// line, zero between launches (the kernel resets what it used).  Launches that may run concurrently must not share a set,
-// so every context keeps one set per stream it has been used with; launches on one stream are ordered.
-struct rd_tickets {
+// Per-stream scheduler state of the export kernel.
+//   * Ticket counters (rd_kernels.h, "Scheduling"): up to RD_MAX_BLOCKS / 4 counters, one per 128-byte line.  They must be
+//     zero when a launch starts; the kernel resets what it used, so launches on ONE stream (ordered) can share a set,
+//     launches that may overlap cannot.
+//   * The u32 histogram slab of single-frame renders (RD_MAX_BLOCKS x 768), allocated on first use.
+// A context keeps one entry per stream it has been used with, at most max_entries of them: beyond that the least
+// recently used entry whose work has finished (its `done` event, recorded after every use) is handed to the new stream.
+// An entry is marked dirty when a launch on it failed or a synchronisation reported an error -- the counters may then be
+// anything -- and is re-zeroed on its stream before the next launch.
+struct rd_scratch {
+    struct entry {
+        hipStream_t stream = nullptr;
+        uint32_t *tq = nullptr;
+        uint32_t *slab32 = nullptr;
+        hipEvent_t done = nullptr;
+        bool dirty = false;
+        uint64_t stamp = 0;
+    };
+    struct lease { uint32_t *tq = nullptr; uint32_t *slab32 = nullptr; int idx = -1; };
+    static constexpr size_t tq_bytes = (size_t)(RD_MAX_BLOCKS / 4) * RD_TQ_STRIDE * sizeof(uint32_t);
+    static constexpr size_t slab_bytes = (size_t)RD_MAX_BLOCKS * 768 * sizeof(uint32_t);
+    static constexpr size_t max_entries = 16;
     std::mutex mu;
-    std::map<hipStream_t, uint32_t *> sets;
-    static constexpr size_t bytes = (size_t)(RD_MAX_BLOCKS / 4) * RD_TQ_STRIDE * sizeof(uint32_t);
-    uint32_t *get(hipStream_t s)
+    std::vector<entry> ents;
+    uint64_t clock = 0;
+
+    // The entry of stream s, created / recycled / re-zeroed as needed.  idx < 0: allocation failed.
+    lease get(hipStream_t s, bool want_slab)
     {
         std::lock_guard<std::mutex> lk(mu);
-        auto it = sets.find(s);
-        if (it != sets.end()) return it->second;
-        uint32_t *d = nullptr;
-        if (hipMalloc((void **)&d, bytes) != hipSuccess) return nullptr;
-        if (hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(d); return nullptr; }
-        sets[s] = d;
-        return d;
+        int idx = -1;
+        for (size_t i = 0; i < ents.size(); ++i)
+            if (ents[i].stream == s) idx = (int)i;
+        if (idx < 0 && ents.size() < max_entries) {
+            entry e;
+            if (hipMalloc((void **)&e.tq, tq_bytes) != hipSuccess) return lease{};
+            if (hipMemset(e.tq, 0, tq_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess) {
+                (void)hipFree(e.tq);
+                return lease{};
+            }
+            e.stream = s;
+            ents.push_back(e);
+            idx = (int)ents.size() - 1;
+        }
+        if (idx < 0) {                                           // recycle: least recently used among the finished ones
+            int lru_done = -1, lru_any = 0;
+            for (size_t i = 0; i < ents.size(); ++i) {
+                if (ents[i].stamp < ents[(size_t)lru_any].stamp) lru_any = (int)i;
+                if (hipEventQuery(ents[i].done) == hipSuccess && (lru_done < 0 || ents[i].stamp < ents[(size_t)lru_done].stamp))
+                    lru_done = (int)i;
+            }
+            idx = lru_done >= 0 ? lru_done : lru_any;
+            if (lru_done < 0 && hipEventSynchronize(ents[(size_t)idx].done) != hipSuccess) ents[(size_t)idx].dirty = true;
+            ents[(size_t)idx].stream = s;
+        }
+        entry &e = ents[(size_t)idx];
+        if (e.dirty) {
+            if (hipMemsetAsync(e.tq, 0, tq_bytes, s) != hipSuccess) return lease{};
+            e.dirty = false;
+        }
+        if (want_slab && !e.slab32 && hipMalloc((void **)&e.slab32, slab_bytes) != hipSuccess) return lease{};
+        e.stamp = ++clock;
+        return lease{ e.tq, e.slab32, idx };
     }
-    void release()                   // caller has synchronised the device
+    void used(const lease &l, hipStream_t s, bool failed)       // after the launches of one call on entry l
     {
         std::lock_guard<std::mutex> lk(mu);
-        for (auto &kv : sets) (void)hipFree(kv.second);
-        sets.clear();
+        if (l.idx < 0 || (size_t)l.idx >= ents.size()) return;
+        if (failed) ents[(size_t)l.idx].dirty = true;
+        if (hipEventRecord(ents[(size_t)l.idx].done, s) != hipSuccess) ents[(size_t)l.idx].dirty = true;
+    }
+    void mark_all_dirty()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : ents) e.dirty = true;
+    }
+    bool poison(hipStream_t s)                                   // test hook: garbage in the counters, as after an aborted launch
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : ents)
+            if (e.stream == s) { e.dirty = true; return hipMemsetAsync(e.tq, 0xa5, tq_bytes, s) == hipSuccess; }
+        return false;
+    }
+    size_t size() { std::lock_guard<std::mutex> lk(mu); return ents.size(); }
+    void release()                                               // caller has synchronised the device
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : ents) {
+            if (e.tq) (void)hipFree(e.tq);
+            if (e.slab32) (void)hipFree(e.slab32);
+            if (e.done) (void)hipEventDestroy(e.done);
+        }
+        ents.clear();
     }
 };
 
@@ -297,12 +368,13 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
                              uint32_t tw, uint32_t th, uint32_t fmt, void *out, const rd_ku &u,
                              bool use_quads, uint32_t unit0, uint32_t unit1, bool hist, uint32_t math,
                              uint32_t *slab32, unsigned long long *slab64, uint32_t fixed_blocks,
-                             rd_tickets &tickets, hipStream_t s, uint32_t *blocks_out)
+                             uint32_t *tq, hipStream_t s, uint32_t *blocks_out)
 {
     uint32_t blocks;
+    (void)hipGetLastError();                     // HIP's last-error slot is sticky per thread: what is read after the launch
+                                                 // below must be THIS launch's, not an earlier failed call's
     if (use_quads) {
-        uint32_t *tq = tickets.get(s);
-        if (!tq) return rd_fail(RD_ERR_OOM, "ticket counter allocation failed");
+        if (!tq) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
         const uint64_t items = (uint64_t)(unit1 - unit0) * (((W >> 1) + 63u) / 64u) * 64u;   // lanes
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
@@ -336,9 +408,8 @@ struct rd_pipeline {
     // scratch
     hipStream_t stream = nullptr;
     void *out_buf = nullptr; size_t out_cap = 0;
-    uint32_t *slab32 = nullptr;       // RD_MAX_BLOCKS x 768
-    uint32_t *hist_dev = nullptr;     // 768
-    rd_tickets tickets;
+    uint32_t *hist_dev = nullptr;     // 768, for the synchronous entry points (used under mu, on `stream`)
+    rd_scratch scratch;               // per stream: ticket counters + histogram slab
     std::mutex mu;                    // uniforms + scratch (Send + Sync like Arc<RenderPipeline>)
 };
 
@@ -371,7 +442,6 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
     p->identity_ok = rd_identity_map(w) && rd_identity_map(h);
 
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->slab32, (size_t)RD_MAX_BLOCKS * 768 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p->hist_dev, 768 * sizeof(uint32_t));
     if (e == hipSuccess) {
         if (cfa_on_device) {
@@ -416,10 +486,9 @@ extern "C" void rd_pipeline_destroy(rd_pipeline *p)
         if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
         if (p->owns_cfa && p->cfa) (void)hipFree((void *)p->cfa);
         if (p->out_buf) (void)hipFree(p->out_buf);
-        if (p->slab32) (void)hipFree(p->slab32);
         if (p->hist_dev) (void)hipFree(p->hist_dev);
         (void)hipDeviceSynchronize();        // renders enqueued on caller streams (rd_render_device) may still draw tickets
-        p->tickets.release();
+        p->scratch.release();
     }
     delete p;
 }
@@ -476,14 +545,17 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
                        (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
                        (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
     uint32_t blocks = 0;
+    const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
+    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
-                               hist_dev != nullptr, p->math_mode, p->slab32, nullptr, 0, p->tickets, s, &blocks);
-    if (rc) return rc;
-    if (hist_dev) {
-        hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, s, p->slab32, blocks, hist_dev);
-        RD_HIP(hipGetLastError());
+                               hist_dev != nullptr, p->math_mode, l.slab32, nullptr, 0, l.tq, s, &blocks);
+    if (rc == RD_OK && hist_dev) {
+        hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, s, l.slab32, blocks, hist_dev);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "histogram fold launch failed: %s", hipGetErrorString(e));
     }
-    return RD_OK;
+    p->scratch.used(l, s, rc != RD_OK);
+    return rc;
 }
 
 extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst_dev,
@@ -515,9 +587,13 @@ extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_
     }
     int rc = rd_pipeline_enqueue(p, out_w, out_h, fmt, p->out_buf, hist ? p->hist_dev : nullptr, p->stream);
     if (rc) return rc;
-    RD_HIP(hipMemcpyAsync(dst, p->out_buf, need, hipMemcpyDeviceToHost, p->stream));
-    if (hist) RD_HIP(hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
-    RD_HIP(hipStreamSynchronize(p->stream));
+    hipError_t e = hipMemcpyAsync(dst, p->out_buf, need, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && hist) e = hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) {                                    // whatever ran may have stopped half way: counters are suspect
+        p->scratch.mark_all_dirty();
+        return rd_fail(RD_ERR_HIP, "render readback failed: %s", hipGetErrorString(e));
+    }
     return RD_OK;
 }
 
@@ -556,10 +632,14 @@ extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_
     }
     RD_HIP(hipMemcpyAsync(p->out_buf, rgba, rgba_len, hipMemcpyHostToDevice, p->stream));
     const uint32_t blocks = rd_blocks_for(p->cfg, npx, true);
+    const rd_scratch::lease l = p->scratch.get(p->stream, true);
+    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, p->stream, (const uint32_t *)p->out_buf,
-                       (uint32_t)npx, p->slab32);
-    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, p->stream, p->slab32, blocks, p->hist_dev);
-    RD_HIP(hipGetLastError());
+                       (uint32_t)npx, l.slab32);
+    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, p->stream, l.slab32, blocks, p->hist_dev);
+    const hipError_t le = hipGetLastError();
+    p->scratch.used(l, p->stream, le != hipSuccess);
+    RD_HIP(le);
     RD_HIP(hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
     RD_HIP(hipStreamSynchronize(p->stream));
     return RD_OK;
@@ -584,7 +664,7 @@ struct rd_batch {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *slab64 = nullptr;      // n_streams x blocks x 768
-    rd_tickets tickets;
+    rd_scratch scratch;                        // per stream: ticket counters
     // Multi-frame launches (the default; RD_BATCH_PERSISTENT=0 falls back to one launch per frame / row band): the
     // frames of a call reach the kernel as an array of descriptors in HBM.  Two arrays with pinned staging; an array is
     // rewritten only when the caller's frames differ from what it holds (bench.py re-submits the same batch every
@@ -662,7 +742,7 @@ extern "C" void rd_batch_destroy(rd_batch *b)
         rd_devguard g(b->device);
         (void)hipDeviceSynchronize();        // launches on the caller's streams still use the slab and the tickets
         if (b->slab64) (void)hipFree(b->slab64);
-        b->tickets.release();
+        b->scratch.release();
         for (auto &d : b->db) {
             if (d.dev) (void)hipFree(d.dev);
             if (d.host) (void)hipHostFree(d.host);
@@ -742,10 +822,12 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     if (kmax > 4096) kmax = 4096;
     if (b->max_frames && b->max_frames < kmax) kmax = b->max_frames;
     if (kmax < 1) kmax = 1;
-    uint32_t *tq = b->tickets.get(s);
-    if (!tq) return rd_fail(RD_ERR_OOM, "ticket counter allocation failed");
+    const rd_scratch::lease l = b->scratch.get(s, false);
+    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    uint32_t *tq = l.tq;
     int rc = RD_OK;
     b->last_launches = 0;
+    (void)hipGetLastError();                     // see rd_enqueue_render
     for (size_t i0 = 0; i0 < n && rc == RD_OK;) {
         size_t c = 1;
         for (; i0 + c < n && c < kmax; ++c) {                               // grow while the next surface overlaps none in the launch
@@ -764,6 +846,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
         else b->last_launches += 1;
         i0 += c;
     }
+    b->scratch.used(l, s, rc != RD_OK);
     RD_HIP(hipEventRecord(b->db[j].done, s));
     return rc;
 }
@@ -787,6 +870,9 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
     int rc = RD_OK;
     size_t launch = 0;
     b->last_launches = 0;
+    rd_scratch::lease ls[2] = { b->scratch.get(lanes[0], false), rd_scratch::lease{} };
+    if (fork) ls[1] = b->scratch.get(lanes[1], false);
+    if (ls[0].idx < 0 || (fork && ls[1].idx < 0)) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     for (size_t f = 0; f < n && rc == RD_OK; ++f) {
         const rd_frame &fr = frames[f];
         if (!fr.cfa_dev || !fr.out_dev) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f); break; }
@@ -800,10 +886,12 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
             const size_t lane = fork ? (launch & 1u) : 0u;
             unsigned long long *slab = b->slab64 ? b->slab64 + lane * (size_t)b->blocks * 768u : nullptr;
             rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0, u1,
-                                   b->hist, b->math_mode, nullptr, slab, b->blocks, b->tickets, lanes[lane], nullptr);
+                                   b->hist, b->math_mode, nullptr, slab, b->blocks, ls[lane].tq, lanes[lane], nullptr);
             if (rc == RD_OK) b->last_launches += 1;
         }
     }
+    b->scratch.used(ls[0], lanes[0], rc != RD_OK);
+    if (fork) b->scratch.used(ls[1], lanes[1], rc != RD_OK);
     if (fork) {                                  // join even after an error: what was enqueued stays ordered
         RD_HIP(hipEventRecord(b->ev_join, b->aux));
         RD_HIP(hipStreamWaitEvent(lanes[0], b->ev_join, 0));
@@ -897,16 +985,19 @@ extern "C" void rd_node_batch_destroy(rd_node_batch *nb)
 {
     if (!nb) return;
     for (uint32_t d = 0; d < nb->n; ++d) {
+        if (d >= nb->streams.size() || !nb->streams[d]) continue;      // nothing was set up on this entry (failed create)
         rd_devguard g(nb->devices[d]);
-        if (d < nb->streams.size() && nb->streams[d]) (void)hipStreamSynchronize(nb->streams[d]);
+        (void)hipStreamSynchronize(nb->streams[d]);
     }
     if (nb->reduce == RD_NODE_REDUCE_RCCL && rd_rccl().ok)
         for (void *c : nb->comms) if (c) (void)rd_rccl().CommDestroy(c);
     for (uint32_t d = 0; d < nb->n; ++d) {
         if (d < nb->batches.size()) rd_batch_destroy(nb->batches[d]);
+        const bool any = (d < nb->hist_dev.size() && nb->hist_dev[d]) || (d < nb->streams.size() && nb->streams[d]);
+        if (!any) continue;
         rd_devguard g(nb->devices[d]);
-        if (d < nb->hist_dev.size() && nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
-        if (d < nb->streams.size() && nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
+        if (nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
+        if (nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
     }
     delete nb;
 }
@@ -1055,7 +1146,7 @@ struct rd_exporter {
     rd_launch_cfg cfg;
     hipStream_t compute = nullptr, copy = nullptr;
     rd_export_slot *slots = nullptr;
-    rd_tickets tickets;
+    rd_scratch scratch;
     std::mutex mu;
 };
 
@@ -1074,7 +1165,7 @@ extern "C" void rd_exporter_destroy(rd_exporter *e)
         }
         if (e->compute) (void)hipStreamDestroy(e->compute);
         if (e->copy) (void)hipStreamDestroy(e->copy);
-        e->tickets.release();
+        e->scratch.release();
     }
     delete[] e->slots;
     delete e;
@@ -1134,8 +1225,11 @@ extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *
     // the previous copy out of this HBM slot must have finished before the kernel overwrites it
     if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
     const rd_ku u = rd_make_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode);
+    const rd_scratch::lease l = e->scratch.get(e->compute, false);
+    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
-                               e->math_mode, nullptr, nullptr, 0, e->tickets, e->compute, nullptr);
+                               e->math_mode, nullptr, nullptr, 0, l.tq, e->compute, nullptr);
+    e->scratch.used(l, e->compute, rc != RD_OK);
     if (rc) return rc;
     RD_HIP(hipEventRecord(s.kernel_done, e->compute));
     RD_HIP(hipStreamWaitEvent(e->copy, s.kernel_done, 0));
@@ -1274,6 +1368,48 @@ extern "C" int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t 
     RD_HIP(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
     return RD_OK;
 }
+
+extern "C" int rd_stream_create(int device, void **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    hipStream_t s = nullptr;
+    RD_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void *)s;
+    return RD_OK;
+}
+
+extern "C" int rd_stream_synchronize(int device, void *stream)
+{
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RD_OK;
+}
+
+extern "C" int rd_stream_destroy(int device, void *stream)
+{
+    if (!stream) return RD_OK;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipStreamDestroy((hipStream_t)stream));
+    return RD_OK;
+}
+
+// Test hooks (declared in rawdev.h under "test hooks"): never needed by a host.
+extern "C" int rd_debug_poison_scheduler(rd_pipeline *p, void *stream)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    rd_devguard g(p->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+    std::lock_guard<std::mutex> lk(p->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    if (!p->scratch.poison(s)) return rd_fail(RD_ERR_INVALID_ARG, "this pipeline holds no scheduler state for that stream yet");
+    return RD_OK;
+}
+
+extern "C" uint32_t rd_debug_scheduler_entries(rd_pipeline *p) { return p ? (uint32_t)p->scratch.size() : 0u; }
 
 extern "C" int rd_device_synchronize(int device)
 {
