@@ -58,34 +58,27 @@ def parse_args():
 
 
 def cpu_baseline(width, height, budget_s):
-    """The oracle, row-parallel over every host core, on whole frames of the same workload."""
+    """The oracle (a port: the reference has no CPU path) on the host cores, whole frames of the same workload.
+    oracle/develop_ref.c::ref_bench_mt: one persistent thread per core, each owning a row band and a band buffer it
+    first-touched itself (no per-frame thread creation, no remote-node page placement), frames separated by barriers."""
+    import ctypes as C
     import numpy as np
     from oracle import ref_c
+    from raweditor_amd import EditParams, FIELDS
     cores = os.cpu_count() or 1
     rng = np.random.default_rng([SEED, 0])
     cfa = rng.integers(0, 4096, (height, width), dtype=np.uint16)
-    from raweditor_amd import EditParams, FIELDS
     p = EditParams.random(np.random.default_rng([SEED, 1]))
     u = ref_c.make_uniforms({f: getattr(p, f) for f in FIELDS}, WB, CM)
-    out = np.empty((height, width, 4), np.float32)
-    import ctypes as C
     L = ref_c.lib()
-    args = (cfa.ctypes.data_as(C.POINTER(C.c_uint16)), width, height, C.byref(u), width, height, 0,
-            out.ctypes.data_as(C.POINTER(C.c_float)), cores)
-    frames, t0 = 0, time.perf_counter()
-    while True:
-        L.ref_render_f32_mt(*args)
-        frames += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or frames >= 16:
-            break
-    mp = frames * width * height / 1e6
+    cp = cfa.ctypes.data_as(C.POINTER(C.c_uint16))
+    fr, sec = C.c_int(), C.c_double()
+    L.ref_bench_mt(cp, width, height, C.byref(u), cores, float(budget_s), 4096, C.byref(fr), C.byref(sec))
+    frames, el = fr.value, sec.value
     # one-thread figure on a 256-row band of the same frame (SURVEY.md section 8d)
     band_h = min(256, height)
-    t1 = time.perf_counter()
-    L.ref_render_f32_mt(cfa.ctypes.data_as(C.POINTER(C.c_uint16)), width, band_h, C.byref(u), width, band_h, 0,
-                        out.ctypes.data_as(C.POINTER(C.c_float)), 1)
-    one_thread = width * band_h / 1e6 / (time.perf_counter() - t1)
+    L.ref_bench_mt(cp, width, band_h, C.byref(u), 1, min(2.0, float(budget_s)), 64, C.byref(fr), C.byref(sec))
+    one_thread = fr.value * width * band_h / 1e6 / sec.value
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -95,10 +88,13 @@ def cpu_baseline(width, height, budget_s):
                     break
     except OSError:
         pass
-    return {"value": round(mp / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+    mpps = frames * width * height / 1e6 / el
+    return {"value": round(mpps, 2), "unit": "MP/s", "cores": cores, "kind": "port",
             "one_thread_MPps": round(one_thread, 2),
-            "sample": f"{frames} x {width}x{height} frame(s), randomised stack, f32 surface, "
-                      f"{el:.1f} s on {cores} threads ({model})"}
+            "parallel_efficiency": round(mpps / (one_thread * cores), 3),
+            "sample": f"{frames} x {width}x{height} frame(s), randomised stack, f32 surface, {el:.1f} s on {cores} "
+                      f"persistent threads with first-touch row bands ({model}); scalar f32 port of the shader, no SIMD: "
+                      f"arithmetic-bound (one thread: {one_thread:.1f} MP/s), reported-only"}
 
 
 def verify_outputs(ra, fmt_name, W, H, cfas, params, ring, n_frames, row_bands, math_name):

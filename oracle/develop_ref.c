@@ -318,6 +318,80 @@ void ref_render_f32_mt(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_un
     free(tid);
 }
 
+/* Timing harness for bench.py's cpu_baseline leg: `nthreads` persistent threads, each owning one row band of the frame
+ * and a band-sized output buffer that it allocates and first-touches itself (so the pages sit on the thread's own NUMA
+ * node), all rendering the same frame again and again between barriers until `budget_s` seconds have passed.
+ * *frames_done / *seconds give whole-frame throughput.  The pixels are the same ref_pixel() arithmetic as everywhere
+ * else; they are not returned (parity is the tests' business, this only measures). */
+typedef struct {
+    const uint16_t *cfa; uint32_t w, h; const ref_uniforms *u; uint32_t row0, row1; int pow_mode;
+    pthread_barrier_t *bar; volatile int *stop; double sink;
+} bench_job;
+
+static void *bench_main(void *arg)
+{
+    bench_job *b = (bench_job *)arg;
+    const size_t n = (size_t)(b->row1 - b->row0) * b->w * 4;
+    float *band = (float *)malloc(n * sizeof(float));
+    if (band) memset(band, 0, n * sizeof(float));            /* first touch by the owning thread */
+    for (;;) {
+        pthread_barrier_wait(b->bar);                        /* frame start (thread 0 decides about stopping in between) */
+        if (*b->stop) break;
+        if (band) {
+            ref_render_f32_band(b->cfa, b->w, b->h, b->u, b->w, b->h, b->row0, b->row1, b->pow_mode, band);
+            b->sink += band[n - 4];
+        }
+        pthread_barrier_wait(b->bar);                        /* frame end */
+    }
+    free(band);
+    return NULL;
+}
+
+#include <time.h>
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void ref_bench_mt(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u, int nthreads, double budget_s,
+                  int max_frames, int *frames_done, double *seconds)
+{
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > h) nthreads = (int)h;
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    bench_job *jobs = (bench_job *)malloc(sizeof(bench_job) * (size_t)nthreads);
+    pthread_barrier_t bar;
+    volatile int stop = 0;
+    pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1u);       /* workers + this thread */
+    for (int t = 0; t < nthreads; ++t) {
+        uint32_t r0 = (uint32_t)(((uint64_t)h * (uint64_t)t) / (uint64_t)nthreads);
+        uint32_t r1 = (uint32_t)(((uint64_t)h * (uint64_t)(t + 1)) / (uint64_t)nthreads);
+        jobs[t] = (bench_job){ cfa, w, h, u, r0, r1, REF_POW_PINNED, &bar, &stop, 0.0 };
+        pthread_create(&tid[t], NULL, bench_main, &jobs[t]);
+    }
+    /* one untimed frame (page faults, clocks), then the timed ones */
+    pthread_barrier_wait(&bar); pthread_barrier_wait(&bar);
+    int frames = 0;
+    const double t0 = now_s();
+    double el = 0.0;
+    do {
+        pthread_barrier_wait(&bar);
+        pthread_barrier_wait(&bar);
+        ++frames;
+        el = now_s() - t0;
+    } while (el < budget_s && frames < max_frames);
+    stop = 1;
+    pthread_barrier_wait(&bar);
+    for (int t = 0; t < nthreads; ++t) pthread_join(tid[t], NULL);
+    pthread_barrier_destroy(&bar);
+    free(jobs);
+    free(tid);
+    if (frames_done) *frames_done = frames;
+    if (seconds) *seconds = el;
+}
+
 /* pipeline.rs:322 Rgba8Unorm store: round-to-nearest of x*255, pinned as trunc(x*255 + 0.5). */
 void ref_pack_u8(const float *rgba, size_t nfloats, uint8_t *out)
 {

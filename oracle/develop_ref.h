@@ -81,6 +81,10 @@ void ref_render_f32(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_unifo
 void ref_render_f32_mt(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u,
                        uint32_t tw, uint32_t th, int pow_mode, float *out, int nthreads);
 
+/* Timing harness (bench.py cpu_baseline): persistent threads, first-touch band buffers, whole frames until budget_s. */
+void ref_bench_mt(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *u, int nthreads, double budget_s,
+                  int max_frames, int *frames_done, double *seconds);
+
 void ref_pack_u8(const float *rgba, size_t nfloats, uint8_t *out);   /* Rgba8Unorm store */
 void ref_pack_f16(const float *rgba, size_t nfloats, uint16_t *out); /* IEEE binary16, RNE */
 void ref_histogram(const uint8_t *rgba, size_t npx, uint32_t hist[768]); /* pipeline.rs:720-736 */

@@ -59,6 +59,9 @@ def lib():
         L.ref_render_f32_band.argtypes = [u16p, C.c_uint32, C.c_uint32, UP, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint32, C.c_int, f32p]
         L.ref_render_f32_band.restype = None
+        L.ref_bench_mt.argtypes = [u16p, C.c_uint32, C.c_uint32, UP, C.c_int, C.c_double, C.c_int,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.ref_bench_mt.restype = None
         L.ref_pack_u8.argtypes = [f32p, C.c_size_t, u8p]
         L.ref_pack_f16.argtypes = [f32p, C.c_size_t, u16p]
         L.ref_histogram.argtypes = [u8p, C.c_size_t, u32p]

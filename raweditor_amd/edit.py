@@ -68,6 +68,10 @@ class EditParams:
         missing = [f for f in FIELDS if f not in obj]
         if missing:
             raise ValueError(f"missing field `{missing[0]}`")
+        for f in FIELDS:                          # serde: an f32 field takes a JSON number and nothing else (null, which
+            v = obj[f]                            # to_json writes for a non-finite value, is rejected on the way back in)
+            if isinstance(v, bool) or not isinstance(v, (int, float)):
+                raise ValueError(f"invalid type for `{f}`: expected f32, found {type(v).__name__}")
         return cls(**{f: obj[f] for f in FIELDS})
 
     def is_unedited(self) -> bool:            # edit.rs:115-117

@@ -64,6 +64,7 @@ def samples_to_u16(values: np.ndarray) -> np.ndarray:
     values = np.asarray(values)
     if values.dtype.kind == "f":
         v = values.astype(np.float32) * np.float32(65535.0)
+        v = np.nan_to_num(v, nan=0.0, posinf=65535.0, neginf=0.0)     # Rust's saturating `as u16`: NaN -> 0
         return np.clip(v, np.float32(0.0), np.float32(65535.0)).astype(np.uint16)
     return values.astype(np.uint16, copy=False)
 
@@ -89,13 +90,31 @@ TAG_COLOR_MATRIX1, TAG_AS_SHOT_NEUTRAL = 50721, 50728
 PHOTOMETRIC_CFA = 32803
 
 
+MAX_IFDS = 64                       # a DNG has a handful; a file that chains more is damaged or hostile
+
+
+def _decode_error(msg: str) -> ValueError:
+    return ValueError(f"Failed to decode RAW: {msg}")           # the reference's error text (loader.rs:50-54)
+
+
 def _read_ifd(buf: bytes, off: int, e: str):
+    """One IFD.  The file is not trusted: every offset and size is checked against the buffer."""
+    if off + 2 > len(buf):
+        raise _decode_error(f"IFD offset {off} is outside the file")
     (n,) = struct.unpack_from(e + "H", buf, off)
+    if off + 2 + 12 * n + 4 > len(buf):
+        raise _decode_error(f"IFD at {off} with {n} entries runs past the end of the file")
     tags = {}
     for i in range(n):
         tag, typ, cnt, val = struct.unpack_from(e + "HHI4s", buf, off + 2 + 12 * i)
         size = _TYPE_SIZE.get(typ, 1) * cnt
-        raw = val[:size] if size <= 4 else buf[struct.unpack(e + "I", val)[0]:][:size]
+        if size <= 4:
+            raw = val[:size]
+        else:
+            (vo,) = struct.unpack(e + "I", val)
+            if vo + size > len(buf):
+                raise _decode_error(f"tag {tag}: value ({size} bytes at {vo}) is outside the file")
+            raw = buf[vo:vo + size]
         if typ in (5, 10):                                  # (S)RATIONAL
             ints = struct.unpack(e + ("I" if typ == 5 else "i") * (2 * cnt), raw)
             vals = [ints[2 * k] / ints[2 * k + 1] if ints[2 * k + 1] else 0.0 for k in range(cnt)]
@@ -114,6 +133,8 @@ def load_dng_uncompressed(path: str) -> RawDataResult:
         raise FileNotFoundError(f"File not found: {path}")
     with open(path, "rb") as fh:
         buf = fh.read()
+    if len(buf) < 8:
+        raise _decode_error("not a TIFF container")
     if buf[:2] == b"II":
         e = "<"
     elif buf[:2] == b"MM":
@@ -123,21 +144,32 @@ def load_dng_uncompressed(path: str) -> RawDataResult:
     magic, off = struct.unpack_from(e + "HI", buf, 2)
     if magic != 42:
         raise ValueError("Failed to decode RAW: bad TIFF magic")
-    todo, ifds = [off], []
+    todo, ifds, seen = [off], [], set()
     while todo:
         o = todo.pop(0)
-        if not o or o >= len(buf):
+        if not o or o in seen:                                  # 0 ends a chain; an offset seen before is a loop
             continue
+        seen.add(o)
+        if len(ifds) >= MAX_IFDS:
+            raise _decode_error(f"more than {MAX_IFDS} IFDs")
         tags, nxt = _read_ifd(buf, o, e)
         ifds.append(tags)
-        todo.extend(tags.get(TAG_SUBIFD, []))
+        todo.extend(int(x) for x in tags.get(TAG_SUBIFD, []) if isinstance(x, int))
         todo.append(nxt)
     raw = next((t for t in ifds if t.get(TAG_PHOTOMETRIC, [None])[0] == PHOTOMETRIC_CFA), None)
     if raw is None:
         raise ValueError("Failed to decode RAW: no CFA image in the file")
     if raw.get(TAG_COMPRESSION, [1])[0] != 1 or raw.get(TAG_BITS, [0])[0] != 16 or raw.get(TAG_SPP, [1])[0] != 1:
         raise ValueError("Failed to decode RAW: only uncompressed 16-bit single-sample CFA data is supported")
+    for need in (TAG_WIDTH, TAG_LENGTH, TAG_STRIP_OFFSETS, TAG_STRIP_BYTES):
+        if not raw.get(need):
+            raise _decode_error(f"CFA image lacks tag {need}")
     w, h = raw[TAG_WIDTH][0], raw[TAG_LENGTH][0]
+    if len(raw[TAG_STRIP_OFFSETS]) != len(raw[TAG_STRIP_BYTES]):
+        raise _decode_error("StripOffsets and StripByteCounts differ in length")
+    for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES]):
+        if o + nbytes > len(buf) or nbytes % 2:
+            raise _decode_error(f"strip ({nbytes} bytes at {o}) is outside the file or not whole samples")
     parts = [np.frombuffer(buf, dtype=e + "u2", count=nbytes // 2, offset=o)
              for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES])]
     data = np.concatenate(parts).astype(np.uint16) if len(parts) > 1 else parts[0].astype(np.uint16)

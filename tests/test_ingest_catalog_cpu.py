@@ -130,3 +130,65 @@ def test_uncompressed_dng(tmp_path, rng, endian):
     (tmp_path / "junk.dng").write_bytes(b"not a tiff at all")
     with pytest.raises(ValueError, match="Failed to decode RAW"):
         ingest.load_dng_uncompressed(str(tmp_path / "junk.dng"))
+
+
+def test_damaged_tiff_containers_fail_cleanly(tmp_path, rng):
+    """The file is not trusted: an IFD chain that loops, offsets and sizes that point outside the
+    file, missing strip tags and short files all end in the reference's "Failed to decode RAW" error
+    (loader.rs:50-54) -- never in a hang, a struct.error or silently truncated data."""
+    cfa = rng.integers(0, 16384, (6, 8), dtype=np.uint16)
+    good = tmp_path / "good.dng"
+    _write_dng(good, cfa, "<", strips=2)
+    buf = bytearray(good.read_bytes())
+    (n0,) = struct.unpack_from("<H", buf, 8)
+    next_off_pos = 8 + 2 + 12 * n0
+
+    def variant(name, edit):
+        b = bytearray(buf)
+        edit(b)
+        p = tmp_path / name
+        p.write_bytes(bytes(b))
+        return str(p)
+
+    # next-IFD pointer of IFD0 points back at IFD0: terminates, and still finds the CFA image
+    loop = variant("loop.dng", lambda b: struct.pack_into("<I", b, next_off_pos, 8))
+    r = ingest.load_dng_uncompressed(loop)
+    assert np.array_equal(r.data.reshape(6, 8), cfa)
+    # next-IFD pointer outside the file
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.load_dng_uncompressed(variant("far.dng", lambda b: struct.pack_into("<I", b, next_off_pos, len(b) + 100)))
+    # truncated file: strips run past the end
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        p = tmp_path / "short.dng"
+        p.write_bytes(bytes(buf[:-20]))
+        ingest.load_dng_uncompressed(str(p))
+    # a value offset outside the file (the ColorMatrix1 blob of IFD0)
+    def break_value_offset(b):
+        for i in range(n0):
+            tag, typ, cnt, val = struct.unpack_from("<HHII", b, 10 + 12 * i)
+            if tag == 50721:
+                struct.pack_into("<I", b, 10 + 12 * i + 8, len(b) - 4)
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.load_dng_uncompressed(variant("val.dng", break_value_offset))
+    for tiny in (b"", b"II*\x00", b"II*\x00\x08\x00\x00\x00"):
+        p = tmp_path / "tiny.dng"
+        p.write_bytes(tiny)
+        with pytest.raises(ValueError, match="Failed to decode RAW"):
+            ingest.load_dng_uncompressed(str(p))
+
+
+def test_float_samples_and_json_edges():
+    """loader.rs:62-73 casts with Rust's saturating `as u16` (NaN -> 0); serde rejects null for an f32 field."""
+    v = np.array([np.nan, -1.0, 0.5, 2.0, np.inf, -np.inf], np.float32)
+    assert ingest.samples_to_u16(v).tolist() == [0, 0, 32767, 65535, 65535, 0]
+    from raweditor_amd import EditParams
+    p = EditParams(exposure=float("nan"))
+    text = p.to_json()
+    assert '"exposure":null' in text
+    with pytest.raises(ValueError, match="exposure"):
+        EditParams.from_json(text)
+    with pytest.raises(ValueError, match="contrast"):
+        EditParams.from_json(EditParams().to_json().replace('"contrast":0.0', '"contrast":"1"'))
+    with pytest.raises(ValueError):
+        EditParams.from_json(EditParams().to_json().replace('"contrast":0.0', '"contrast":true'))
+    assert EditParams.from_json(EditParams().to_json().replace('"contrast":0.0', '"contrast":3')).contrast == 3.0
