@@ -247,11 +247,13 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             prof = json.load(fh)
-        key = args.format if args.row_bands <= 1 else f"{args.format}_bands{args.row_bands}"
-        ent = prof.get(key, {})
-        if ent and list(ent.get("frame", prof.get("frame", []))) == [W, H] and ent.get("hbm_bytes_per_frame"):
-            traffic = int(ent["hbm_bytes_per_frame"] * F / lpc)             # per launch, like `achieved`
-            traffic_source = f"profiles/pmc_traffic.json[{key}] ({prof.get('tag', 'committed profile')}), not this run"
+        mode = "multi" if lpc < F * max(1, args.row_bands) else "per_frame"
+        for ent in prof.get("entries", []):
+            if ent.get("format") == args.format and list(ent.get("frame", [])) == [W, H] and ent.get("mode") == mode:
+                traffic = int(ent["hbm_bytes_per_frame"] * F / lpc)             # per launch, like `achieved`
+                traffic_source = (f"profiles/pmc_traffic.json [{args.format}, {W}x{H}, {mode}] (rocprofv3 PMC passes of "
+                                  f"{prof.get('tag', 'a committed profile')}), not measured by this run")
+                break
     except (OSError, ValueError):
         pass
 

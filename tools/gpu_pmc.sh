@@ -1,21 +1,39 @@
 #!/bin/bash
-# HBM traffic of the export kernel from the L2 memory-side counters, as MI355X_MICROARCH.md section HBM
-# prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), with
-# --kernel-trace only.  Two variants: RD_BURST=0 (every CFA line read exactly once: the calibration
-# case for our 4-B-per-lane loads) and RD_BURST=1 (the shipped f32 configuration).
+# HBM traffic and SQ activity of the export kernels from rocprofv3 PMC passes, as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), --kernel-trace only, the program itself
+# after "--".  Every pass is one short bench.py run (32 frames per step, ring of 8: multi-frame launches of exactly 8
+# frames; config 5: 8 frames, ring of 4).  tools/parse_pmc.py turns the result into profiles/pmc_traffic.json and a
+# summary; the gfx950 corrections (FETCH_SIZE x2 for 16-B LDS-DMA reads, calibrated on a known volume for 4-B loads)
+# are applied there.
+#   tools/gpu_pmc.sh [tag]      (run from the repository root on the GPU box)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for BURST in 0 1; do
-  for CTR in FETCH_SIZE WRITE_SIZE; do
-    echo "== RD_BURST=$BURST $CTR"
-    RD_BURST=$BURST timeout -k 10 300 rocprofv3 --kernel-trace --pmc $CTR --output-format csv \
-        -d "$OUT/b${BURST}_$CTR" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --frames 32 --no-cpu-baseline \
-        > "$OUT/b${BURST}_$CTR.log" 2>&1
-    rc=$?; echo "rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
-  done
+BENCH="--steps 2 --warmup 1 --frames 32 --no-cpu-baseline --no-alt-math"
+C5="--width 11648 --height 8736 --format f16 --row-bands 8 --frames 8 --ring 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math"
+pass() {   # name, env assignments ("-" for none), counters (comma separated), bench arguments...
+  local name=$1 envs=$2 ctrs=$3; shift 3
+  echo "== $name [$envs] $ctrs"
+  ( [ "$envs" != "-" ] && export $envs
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d "$OUT/$name" -- \
+        python3 "$ROOT/bench.py" "$@" > "$OUT/$name.log" 2>&1 )
+  local rc=$?; echo "rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+}
+for CTR in FETCH_SIZE WRITE_SIZE; do
+  pass f32_multi_$CTR      -                                    $CTR $BENCH
+  pass f32_perframe_noburst_$CTR "RD_BATCH_PERSISTENT=0 RD_BURST=0" $CTR $BENCH
+  pass f32_perframe_$CTR   "RD_BATCH_PERSISTENT=0"              $CTR $BENCH
+  pass f16_multi_$CTR      -                                    $CTR $BENCH --format f16
+  pass u8_multi_$CTR       -                                    $CTR $BENCH --format u8
+  pass c5_multi_$CTR       -                                    $CTR $C5
 done
-cd "$ROOT" && python3 tools/parse_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"
+SQ1=SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_INSTS_VALU,SQ_ACTIVE_INST_VALU,SQ_INST_CYCLES_VMEM_WR,SQ_WAIT_INST_ANY,SQ_WAIT_ANY,SQ_ACTIVE_INST_ANY,GRBM_GUI_ACTIVE
+SQ2=SQ_INSTS_VALU_TRANS_F32,SQ_INSTS_VMEM_WR,SQ_INSTS_VMEM_RD,SQ_INSTS_LDS,SQ_INSTS_SALU,SQ_INSTS_SMEM,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_VMEM,GRBM_GUI_ACTIVE
+pass f32_multi_SQ1 - $SQ1 $BENCH
+pass f32_multi_SQ2 - $SQ2 $BENCH
+pass u8_multi_SQ1  - $SQ1 $BENCH --format u8
+pass f16_multi_SQ1 - $SQ1 $BENCH --format f16
+cd "$ROOT" && python3 tools/parse_pmc.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"
