@@ -57,6 +57,33 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Threads worth starting: the CPUs this process may run on, capped by the cgroup's CPU quota (a GPU box gives a
+    one-GPU job a share of the host -- 256 hardware threads are visible, far fewer can run at once)."""
+    hw = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = hw
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, f"{n} of {hw} hardware threads usable (affinity / cgroup CPU quota)"
+
+
 def cpu_baseline(width, height, budget_s):
     """The oracle (a port: the reference has no CPU path) on the host cores, whole frames of the same workload.
     oracle/develop_ref.c::ref_bench_mt: one persistent thread per core, each owning a row band and a band buffer it
@@ -65,7 +92,7 @@ def cpu_baseline(width, height, budget_s):
     import numpy as np
     from oracle import ref_c
     from raweditor_amd import EditParams, FIELDS
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cores()
     rng = np.random.default_rng([SEED, 0])
     cfa = rng.integers(0, 4096, (height, width), dtype=np.uint16)
     p = EditParams.random(np.random.default_rng([SEED, 1]))
@@ -93,7 +120,7 @@ def cpu_baseline(width, height, budget_s):
             "one_thread_MPps": round(one_thread, 2),
             "parallel_efficiency": round(mpps / (one_thread * cores), 3),
             "sample": f"{frames} x {width}x{height} frame(s), randomised stack, f32 surface, {el:.1f} s on {cores} "
-                      f"persistent threads with first-touch row bands ({model}); scalar f32 port of the shader, no SIMD: "
+                      f"persistent threads with first-touch row bands ({model}; {cores_note}); scalar f32 port of the shader, no SIMD: "
                       f"arithmetic-bound (one thread: {one_thread:.1f} MP/s), reported-only"}
 
 
