@@ -242,6 +242,12 @@ int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64
  * host-side oracle can be compared with them. */
 int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst);
 
+/* The same for the RGBA-f16 surface's shortcut: the binary16 value (and the 8-bit code for the fused histogram) of every
+ * float encoding against binary16(pinned gamma) / the pinned code.  *fallbacks = encodings in binary16's normal range
+ * (gamma >= 2^-14) where the pinned evaluation decides the half; below that range it always does. */
+int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks);
+int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst);
+
 /* ---- plumbing for hosts without a HIP binding (tests, the Python mirror) -------------------- */
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);

@@ -1314,6 +1314,68 @@ extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_
     return RD_OK;
 }
 
+// The same for the binary16 surface's shortcut (rd_f16_gamma): halves and, with the histogram, codes.
+__global__ void __launch_bounds__(256) rd_f16_sweep(uint32_t base, rd_q8_stats *st, uint16_t *halves)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = rd_u2f(base + i);
+    uint32_t h, q, h2, q2;
+    rd_f16_gamma<true>(x, h, q);
+    rd_f16_gamma<false>(x, h2, q2);                          // the variant without the histogram must give the same half
+    const float g = rd_gamma_clamp(x);
+    const uint32_t he = __builtin_bit_cast(uint16_t, (_Float16)g), qe = rd_q8(g);
+    if (halves) halves[i] = (uint16_t)h;
+    if (!st) return;
+    if (h != he || q != qe || h2 != he) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
+    if (x >= RD_FLT_MIN) {                                    // how often the pinned evaluation decides the half
+        const float z = __builtin_amdgcn_logf(x) * RD_INV_GAMMA;
+        const float e = __builtin_fminf(__builtin_amdgcn_exp2f(z), 1.0f);
+        const float lowbits = rd_u2f((rd_f2u(e) & 0x1fffu) | 0x4b000000u) - 8388608.0f;
+        const float k = __builtin_fmaf(__builtin_fabsf(z), RD_F16_KA, RD_F16_KB);
+        if (e >= 6.103515625e-05f && __builtin_fabsf(lowbits - 4096.0f) <= k) atomicAdd(&st->fallbacks, 1ull);   // normal halves only
+    }
+}
+
+extern "C" int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks)
+{
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
+    RD_HIP(hipMalloc((void **)&dst, sizeof st));
+    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
+    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {
+        hipLaunchKernelGGL(rd_f16_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint16_t *)nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16: %s", hipGetErrorString(e));
+    if (mismatches) *mismatches = st.mismatches;
+    if (first_bad) *first_bad = st.first_bad;
+    if (fallbacks) *fallbacks = st.fallbacks;
+    return RD_OK;
+}
+
+extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst)
+{
+    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
+        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_f16_halves: n must be a non-zero multiple of 256 inside the 2^32 encodings");
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    uint16_t *dev = nullptr;
+    RD_HIP(hipMalloc((void **)&dev, (size_t)n * 2));
+    hipLaunchKernelGGL(rd_f16_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(dst, dev, (size_t)n * 2, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16_halves: %s", hipGetErrorString(e));
+    return RD_OK;
+}
+
 extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
 {
     if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))

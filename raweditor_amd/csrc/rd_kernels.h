@@ -243,6 +243,41 @@ __device__ __forceinline__ uint32_t rd_q8_gamma(float x)
     return x >= RD_FLT_MIN ? q : 0u;                             // negative, NaN, zero, subnormal: code 0 (rd_gamma_clamp's cases)
 }
 
+// The same shortcut for the RGBA-f16 surface (BASELINE config 5): what leaves the kernel is the binary16 rounding of the
+// pinned gamma (and, with the fused histogram, its 8-bit code).  The hardware pow e = 2^z, z = log2(x) / 2.2, is within
+// (1.2 |z| + 2.25) * 2^-23 * e of the pinned value -- its error is that of z, which grows with |log2 x|
+// (tools/f16_err_probe.hip: largest relative distance 1.41 * 2^-23 for |z| < 1, 3.9 below 7, 12.1 below 29, 23.2 beyond;
+// the bound keeps 1.5x that) -- i.e. within K = 2.4 |z| + 4.5 of its own f32 ulps.  binary16 keeps 10 of the 23 fraction
+// bits and rounds to nearest, so the pinned value and e round to the same half unless the 13 discarded bits of e lie
+// within K of the midpoint 0x1000; only then (about one lane in 800 for bright pixels), and below binary16's normal
+// range, the pinned evaluation decides.  Checked for all 2^32 encodings against binary16(rd_gamma_clamp(x)) by
+// rd_selftest_f16 / tests/test_gpu_q8.py.
+#define RD_F16_KA 2.4f
+#define RD_F16_KB 4.5f
+template <bool WANT_Q>
+__device__ __forceinline__ void rd_f16_gamma(float x, uint32_t &h, uint32_t &q)
+{
+    const float z = __builtin_amdgcn_logf(x) * RD_INV_GAMMA;
+    const float e = __builtin_fminf(__builtin_amdgcn_exp2f(z), 1.0f);        // x >= 1 and +inf: 1.0
+    // the 13 discarded fraction bits as a float (0 ... 8191, exact): 2^23 + bits is representable, minus 2^23
+    const float lowbits = rd_u2f((rd_f2u(e) & 0x1fffu) | 0x4b000000u) - 8388608.0f;
+    const float k = __builtin_fmaf(__builtin_fabsf(z), RD_F16_KA, RD_F16_KB);
+    bool near = __builtin_fabsf(lowbits - 4096.0f) <= k || e < 6.103515625e-05f;   // near a rounding midpoint, or subnormal half
+    h = __builtin_bit_cast(uint16_t, (_Float16)e);
+    q = 0u;
+    if (WANT_Q) {
+        const float y = __builtin_fmaf(e, 255.0f, 0.5f);                     // <= 255.5
+        q = (uint32_t)y;
+        near = near || __builtin_fabsf(__builtin_amdgcn_fractf(y) - 0.5f) > 0.5f - RD_Q8_EPS;
+    }
+    if (near) {
+        const float g = rd_gamma_clamp(x);
+        h = __builtin_bit_cast(uint16_t, (_Float16)g);
+        if (WANT_Q) q = rd_q8(g);
+    }
+    if (!(x >= RD_FLT_MIN)) { h = 0u; q = 0u; }                  // negative, NaN, zero, subnormal: rd_gamma_clamp gives +0
+}
+
 // ---------------------------------------------------------------------------------------------
 // Histogram: RD_HK private copies of every bin in LDS, copy = lane % RD_HK, so a flat frame (all 64
 // lanes in one bin) serialises 64/RD_HK-deep on an address instead of 64-deep.  RD_HK = 8 keeps the
@@ -514,40 +549,52 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         const bool valid = FULL || (tq * 64u + lane) < qpr;
         const float A = rd_norm(top & 0xffffu, u.black_level), B = rd_norm(top >> 16, u.black_level);
         const float C = rd_norm(bot & 0xffffu, u.black_level), D = rd_norm(bot >> 16, u.black_level);
+#if defined(RD_COLOUR_HOOK_HEADER) || defined(RD_NO_Q8_SHORTCUT)   // microbench stand-ins / A/B builds (tools/): the narrow
+        constexpr bool Q8ONLY = false, H16 = false;                    // surfaces go through the pinned gamma like the f32 one
+#else
+        constexpr bool Q8ONLY = FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8;    // only the 8-bit codes leave the kernel
+        constexpr bool H16 = FMT == RD_FMT_RGBA_F16;                              // only binary16 values (+ codes) leave it
+#endif
 #ifdef RD_COLOUR_HOOK_HEADER
         const rd_rgb c1 = RD_COLOUR(u, C, A, B);
         const rd_rgb c2 = RD_COLOUR(u, C, D, A);
         const rd_rgb c3 = RD_COLOUR(u, C, D, B);
 #else
-#ifdef RD_NO_Q8_SHORTCUT   // A/B builds only (tools/): the 8-bit surfaces go through the pinned gamma like the others
-        constexpr bool Q8ONLY = false;
-#else
-        constexpr bool Q8ONLY = FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8;    // only the 8-bit codes leave the kernel
-#endif
         float tr[3] = { C, C, C }, tg[3] = { A, D, D }, tb[3] = { B, A, B };       // row a: (C,A,B); row b: (C,D,A), (C,D,B)
-        rd_colour_n<3, MATH, !Q8ONLY>(u, tr, tg, tb);
+        rd_colour_n<3, MATH, !(Q8ONLY || H16)>(u, tr, tg, tb);
         const rd_rgb c1 = { tr[0], tg[0], tb[0] }, c2 = { tr[1], tg[1], tb[1] }, c3 = { tr[2], tg[2], tb[2] };
 #endif
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
-#ifndef RD_COLOUR_HOOK_HEADER
+        uint32_t ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0, hc0 = 0, hc1 = 0;       // binary16 pairs (r, g), (b, 1.0) of c1, c2, c3 (H16)
         if constexpr (Q8ONLY) {
             q1r = rd_q8_gamma(c1.r); q1g = rd_q8_gamma(c1.g); q1b = rd_q8_gamma(c1.b);
             q2r = rd_q8_gamma(c2.r); q2g = rd_q8_gamma(c2.g); q2b = rd_q8_gamma(c2.b);
             q3r = rd_q8_gamma(c3.r); q3g = rd_q8_gamma(c3.g); q3b = rd_q8_gamma(c3.b);
-        } else
-#endif
-        if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
+        } else if constexpr (H16) {                               // triple by triple: halves packed and codes counted at once,
+            uint32_t hr, hg, hb;                                  // so that at most one triple's values are live
+            rd_f16_gamma<HIST>(c1.r, hr, q1r); rd_f16_gamma<HIST>(c1.g, hg, q1g); rd_f16_gamma<HIST>(c1.b, hb, q1b);
+            ha0 = hr | (hg << 16); ha1 = hb | 0x3c000000u;
+            if (HIST && valid && has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
+            rd_f16_gamma<HIST>(c2.r, hr, q2r); rd_f16_gamma<HIST>(c2.g, hg, q2g); rd_f16_gamma<HIST>(c2.b, hb, q2b);
+            hb0 = hr | (hg << 16); hb1 = hb | 0x3c000000u;
+            if (HIST && valid && has_b) rd_hist_add(lh, copy, q2r, q2g, q2b, 1u);
+            rd_f16_gamma<HIST>(c3.r, hr, q3r); rd_f16_gamma<HIST>(c3.g, hg, q3g); rd_f16_gamma<HIST>(c3.b, hb, q3b);
+            hc0 = hr | (hg << 16); hc1 = hb | 0x3c000000u;
+            if (HIST && valid && has_b) rd_hist_add(lh, copy, q3r, q3g, q3b, 1u);
+        } else if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
             q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
             q3r = rd_q8(c3.r); q3g = rd_q8(c3.g); q3b = rd_q8(c3.b);
         }
-        if (HIST && valid) {
+        if (HIST && valid && !H16) {
             if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
             if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
         }
         rd_tile_out<FMT> r;
         if constexpr (FMT == RD_FMT_RGBA_F32) {
             r.c1 = c1; r.c2 = c2; r.c3 = c3;
+        } else if constexpr (FMT == RD_FMT_RGBA_F16 && H16) {
+            r.a0 = ha0; r.a1 = ha1; r.b0 = hb0; r.b1 = hb1; r.c0 = hc0; r.c1 = hc1;
         } else if constexpr (FMT == RD_FMT_RGBA_F16) {
             const rd_h2 a_rg = { (_Float16)c1.r, (_Float16)c1.g }, a_b1 = { (_Float16)c1.b, (_Float16)1.0f };
             const rd_h2 b_rg = { (_Float16)c2.r, (_Float16)c2.g }, b_b1 = { (_Float16)c2.b, (_Float16)1.0f };

@@ -73,3 +73,42 @@ def test_q8_shortcut_against_the_oracle(gpu_lib, refc):
         bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
         assert np.array_equal(_codes(ra, first, 256), _oracle_codes(refc, bits)), hex(first)
     assert checked == 255 * 1024
+
+
+def test_f16_shortcut_equals_binary16_of_the_pinned_gamma_for_every_float(gpu_lib):
+    """rd_f16_gamma (the RGBA-f16 surface, BASELINE config 5): for all 2^32 encodings the half is binary16(rd_gamma_clamp(x))
+    and the histogram code is the pinned one, with and without the fused histogram."""
+    from raweditor_amd import _lib
+    bad, first, fb = C.c_uint64(), C.c_uint32(), C.c_uint64()
+    _lib.check(_lib.lib().rd_selftest_f16(0, C.byref(bad), C.byref(first), C.byref(fb)))
+    assert bad.value == 0, f"{bad.value} encodings differ, first 0x{first.value:08x}"
+    assert 0 < fb.value < 31 * 2**23 * 0.02           # of the ~31 binades of x whose gamma is a normal half: a rare path
+
+
+def test_f16_shortcut_against_the_oracle(gpu_lib, refc):
+    from raweditor_amd import _lib
+
+    def halves(first, n):
+        out = np.empty(n, np.uint16)
+        _lib.check(_lib.lib().rd_selftest_f16_halves(0, first, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def oracle_halves(bits):
+        L = refc.lib()
+        x = bits.astype(np.uint32).view(np.float32)
+        g = np.empty_like(x)
+        for i, v in enumerate(x):
+            g[i] = L.ref_powf(C.c_float(v), C.c_float(np.float32(0.45454547)), 0)
+        g = np.minimum(np.where(g > 0, g, np.float32(0)).astype(np.float32), np.float32(1))
+        return refc.pack_f16(g).view(np.uint16)
+
+    rng = np.random.default_rng(16)
+    firsts = [0x00000000, 0x007fff00, 0x00800000, 0x3f7fff00, 0x3f800000, 0x7f7fff00, 0x7f800000, 0x7fc00000, 0x80000000,
+              0xbf800000, 0xff800000, 0xffffff00]
+    # the bright half of the range, where almost all pixels live, densely; then every exponent; then anywhere
+    firsts += [int(v) // 256 * 256 for v in rng.integers(0x3c000000, 0x3f800000, 160, dtype=np.uint64)]
+    firsts += [(e << 23) + (int(m) // 256 * 256) for e in range(1, 255) for m in rng.integers(0, 1 << 23, 1)]
+    firsts += [int(v) // 256 * 256 for v in rng.integers(0, 2**32 - 256, 64, dtype=np.uint64)]
+    for first in firsts:
+        bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
+        assert np.array_equal(halves(first, 256), oracle_halves(bits)), hex(first)
