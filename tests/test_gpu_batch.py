@@ -151,3 +151,63 @@ def test_batch_rejects_bad_arguments(gpu_lib):
     frames = be.make_frames([buf.ptr], [buf.ptr + 4], [ra.EditParams()], WB_DAYLIGHT, CM_TEST)
     with pytest.raises(ra.RawdevError):
         be.develop(frames)                                       # misaligned f32 surface
+
+
+def test_multi_frame_launch_with_heterogeneous_frames(gpu_lib, refc):
+    """One multi-frame launch whose frames differ in everything a descriptor carries: slider stacks that elide different
+    steps (defaults + identity matrix, a few sliders, all ten + camera matrix), white balance, colour matrix and black
+    level -- a wave switches uniforms (and elision branches) when its tiles cross into the next frame.  Burst-eligible
+    size (1024 x 1030, f32), then the same call with one CFA plane at a 4-byte-aligned-only address (the whole call then
+    runs the instantiation without the read burst)."""
+    import ctypes as C
+    from raweditor_amd._lib import RdFrame
+    from tests.helpers import CM_IDENTITY
+    ra = gpu_lib
+    h, w = 1030, 1024
+    rng = np.random.default_rng([0x52415745, 606])
+    stacks = [dict(), dict(exposure=1.0, contrast=5.0), random_params(rng), dict(saturation=40.0, vibrance=-0.5, blacks=0.1),
+              random_params(rng), dict(whites=0.9, temperature=0.3, tint=-0.2, highlights=0.4, shadows=-0.3)]
+    cms = [CM_IDENTITY, CM_IDENTITY, CM_TEST, CM_IDENTITY, CM_TEST, CM_TEST]
+    wbs = [(1, 1, 1, 1), WB_DAYLIGHT, WB_DAYLIGHT, (1.7, 1.0, 1.9, 1.0), (2.2, 1.0, 1.3, 1.0), WB_DAYLIGHT]
+    bls = [0, 0, 64, 0, 0, 256]
+    n = len(stacks)
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    exp, exp_hist = [], np.zeros(768, np.uint64)
+    for c, p, cm, wb, bl in zip(cfas, stacks, cms, wbs, bls):
+        u = refc.make_uniforms(p, wb, cm, black_level=bl)
+        e = refc.render_f32(c, u, nthreads=8)
+        exp.append(e)
+        exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
+    for misalign in (0, 4):
+        d_in = []
+        for i, c in enumerate(cfas):
+            if i == 3 and misalign:                             # this plane starts 4 bytes into its buffer
+                buf = DevBuf(c.nbytes + 16)
+                from raweditor_amd._lib import check
+                from raweditor_amd import _lib
+                check(_lib.lib().rd_memcpy_h2d(0, C.c_void_p(buf.ptr + misalign), c.ctypes.data_as(C.c_void_p), c.nbytes))
+                d_in.append((buf, buf.ptr + misalign))
+            else:
+                buf = DevBuf.from_array(c)
+                d_in.append((buf, buf.ptr))
+        d_out = [DevBuf(h * w * 16) for _ in range(n)]
+        d_hist = DevBuf(768 * 8)
+        be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, True)
+        frames = (RdFrame * n)()
+        for i in range(n):
+            frames[i].cfa_dev = d_in[i][1]
+            frames[i].out_dev = d_out[i].ptr
+            frames[i].params = ra.EditParams(**stacks[i]).to_c()
+            frames[i].wb_multipliers[:] = [float(x) for x in wbs[i]]
+            frames[i].color_matrix[:] = [float(x) for x in cms[i]]
+            frames[i].black_level = bls[i]
+        for rep in range(2):
+            be.develop(frames)
+            assert be.last_launch_count() == 1                  # six frames, one launch
+            be.histogram(d_hist.ptr)
+            sync()
+            for i in range(n):
+                got = d_out[i].to_array(np.float32, (h, w, 4))
+                assert np.array_equal(got.view(np.uint32), exp[i].view(np.uint32)), (misalign, rep, i)
+            assert np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist), (misalign, rep)
+        be.close()
