@@ -58,6 +58,13 @@ typedef enum rd_format {
  *              compiler emits for the reference's shader; ~20 % fewer VALU instructions. */
 typedef enum rd_math_mode { RD_MATH_STRICT = 0, RD_MATH_CONTRACTED = 1 } rd_math_mode;
 
+/* How `color_matrix` (the host's row-major [9]) is applied (its section 8b's rd_options.matrix_layout).
+ *   REFERENCE (default) the reference's behaviour: the shader builds mat3x3(row0, row1, row2), WGSL constructors take
+ *             COLUMNS, so the rows are consumed as columns and out = M^T * c (shaders.rs:209-214).  A no-op for the
+ *             identity matrix, which is all the reference app ever passes (color.rs:35-47).
+ *   ROW_MAJOR the "intended" form out = M * c, for hosts that pass a real camera matrix. */
+typedef enum rd_matrix_layout { RD_MATRIX_REFERENCE = 0, RD_MATRIX_ROW_MAJOR = 1 } rd_matrix_layout;
+
 /* state::edit::EditParams (src/state/edit.rs:15-77): ten f32 in this order; #[repr(C)]-compatible. */
 typedef struct rd_edit_params {
     float exposure;    /* stops, UI range [-5, 5]          (main.rs:1624-1660 for all ranges) */
@@ -121,6 +128,8 @@ int rd_pipeline_info(const rd_pipeline *p, rd_info *out);
 int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t black_level);
 /* Extension: select the arithmetic (rd_math_mode); RD_MATH_STRICT is the default. */
 int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t math_mode);
+/* Extension: how color_matrix is applied (rd_matrix_layout); RD_MATRIX_REFERENCE (rows as columns) is the default. */
+int rd_pipeline_set_matrix_layout(rd_pipeline *p, uint32_t matrix_layout);
 
 /* update_uniforms (pipeline.rs:367) == update_uniforms_with_zoom(params, 1, 0, 0). */
 int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params);
@@ -162,6 +171,7 @@ typedef struct rd_frame {
     float wb_multipliers[4];
     float color_matrix[9];
     uint32_t black_level;
+    uint32_t matrix_layout; /* rd_matrix_layout; 0 = the reference's (rows consumed as columns) */
 } rd_frame;
 
 /* A batch context owns the histogram slab for frames of one size/format on one device.  Use one context per

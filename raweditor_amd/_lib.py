@@ -12,6 +12,7 @@ RD_OK = 0
 ABI_VERSION = 2          # include/rawdev.h RD_ABI_VERSION
 FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8, FMT_RGB_U8 = 0, 1, 2, 3
 MATH_STRICT, MATH_CONTRACTED = 0, 1
+MATRIX_REFERENCE, MATRIX_ROW_MAJOR = 0, 1
 BYTES_PER_PIXEL = {FMT_RGBA_F32: 16, FMT_RGBA_F16: 8, FMT_RGBA_U8: 4, FMT_RGB_U8: 3}
 
 
@@ -40,7 +41,7 @@ class RdInfo(C.Structure):
 class RdFrame(C.Structure):
     _fields_ = [("cfa_dev", C.c_void_p), ("out_dev", C.c_void_p), ("params", RdEditParams),
                 ("wb_multipliers", C.c_float * 4), ("color_matrix", C.c_float * 9),
-                ("black_level", C.c_uint32)]
+                ("black_level", C.c_uint32), ("matrix_layout", C.c_uint32)]
 
 
 # every symbol include/rawdev.h declares: (restype, argtypes)
@@ -61,6 +62,7 @@ PROTOTYPES = {
     "rd_pipeline_info": (_I, [_VP, C.POINTER(RdInfo)]),
     "rd_pipeline_set_black_level": (_I, [_VP, _U32]),
     "rd_pipeline_set_math_mode": (_I, [_VP, _U32]),
+    "rd_pipeline_set_matrix_layout": (_I, [_VP, _U32]),
     "rd_update_uniforms": (_I, [_VP, C.POINTER(RdEditParams)]),
     "rd_update_uniforms_with_zoom": (_I, [_VP, C.POINTER(RdEditParams), C.c_float, C.c_float, C.c_float]),
     "rd_render_to_bytes": (_I, [_VP, _VP, _SZ]),

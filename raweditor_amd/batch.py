@@ -94,7 +94,7 @@ class BatchExporter:
 
     @staticmethod
     def make_frames(cfa_ptrs: Sequence[int], out_ptrs: Sequence[int], params: Sequence[EditParams],
-                    wb: Sequence[float], cm: Sequence[float], black_level: int = 0):
+                    wb: Sequence[float], cm: Sequence[float], black_level: int = 0, matrix_layout: int = 0):
         """Build the rd_frame array once (device pointers as ints); reuse it for every step."""
         n = len(cfa_ptrs)
         if not (len(out_ptrs) == len(params) == n):
@@ -107,6 +107,7 @@ class BatchExporter:
             arr[i].wb_multipliers[:] = [float(x) for x in wb]
             arr[i].color_matrix[:] = [float(x) for x in cm]
             arr[i].black_level = int(black_level)
+            arr[i].matrix_layout = int(matrix_layout)
         return arr
 
     def develop(self, frames, row_bands: int = 1, stream: int = 0) -> None:

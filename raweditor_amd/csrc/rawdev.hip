@@ -131,6 +131,19 @@ static uint32_t rd_env_u32(const char *name, uint32_t dflt)
     return v > 0 ? (uint32_t)v : dflt;
 }
 
+// The uniforms of one frame.  `layout` = RD_MATRIX_REFERENCE hands the host's row-major matrix to the kernel as it is (its
+// rows are then consumed as COLUMNS, shaders.rs:209-214: out = M^T c -- the reference's behaviour); RD_MATRIX_ROW_MAJOR is the
+// opt-in "intended" form out = M c, obtained by transposing on the host (SURVEY.md D4, section 8b rd_options.matrix_layout).
+static rd_ku rd_frame_ku(const rd_edit_params &p, const float wb[4], const float cm[9], float zoom, float pan_x, float pan_y,
+                         uint32_t black_level, uint32_t math_mode, uint32_t layout)
+{
+    if (layout == RD_MATRIX_ROW_MAJOR) {
+        const float t[9] = { cm[0], cm[3], cm[6], cm[1], cm[4], cm[7], cm[2], cm[5], cm[8] };
+        return rd_make_ku(p, wb, t, zoom, pan_x, pan_y, black_level, math_mode);
+    }
+    return rd_make_ku(p, wb, cm, zoom, pan_x, pan_y, black_level, math_mode);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch plumbing shared by pipelines and batches
 // ------------------------------------------------------------------------------------------------
@@ -405,6 +418,7 @@ struct rd_pipeline {
     float zoom = 1.0f, pan_x = 0.0f, pan_y = 0.0f;
     uint32_t black_level = 0;
     uint32_t math_mode = RD_MATH_STRICT;
+    uint32_t matrix_layout = RD_MATRIX_REFERENCE;
     // scratch
     hipStream_t stream = nullptr;
     void *out_buf = nullptr; size_t out_cap = 0;
@@ -508,6 +522,15 @@ extern "C" int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t bl)
     return RD_OK;
 }
 
+extern "C" int rd_pipeline_set_matrix_layout(rd_pipeline *p, uint32_t layout)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    if (layout != RD_MATRIX_REFERENCE && layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", layout);
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->matrix_layout = layout;
+    return RD_OK;
+}
+
 extern "C" int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t mode)
 {
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
@@ -540,7 +563,7 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
     if ((uintptr_t)dst_dev % rd_align_for(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "dst is not %zu-byte aligned", rd_align_for(fmt));
     const uint32_t W = p->info.width, H = p->info.height;
-    const rd_ku u = rd_make_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode);
+    const rd_ku u = rd_frame_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode, p->matrix_layout);
     const bool quads = tw == W && th == H && p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f &&
                        (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
                        (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
@@ -785,7 +808,9 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
         if ((uintptr_t)fr.cfa_dev % 16u) aligned16 = false;
         tmp[f].cfa = fr.cfa_dev;
         tmp[f].out = fr.out_dev;
-        tmp[f].u = rd_make_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level, b->math_mode);
+        if (fr.matrix_layout != RD_MATRIX_REFERENCE && fr.matrix_layout != RD_MATRIX_ROW_MAJOR)
+            return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: unknown matrix layout %u", f, fr.matrix_layout);
+        tmp[f].u = rd_frame_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level, b->math_mode, fr.matrix_layout);
         static const bool no_elide = rd_env_u32("RD_NO_ELIDE", 0) != 0;
         if (no_elide) tmp[f].u.elide = 0u;
     }
@@ -878,8 +903,9 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
         if (!fr.cfa_dev || !fr.out_dev) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f); break; }
         if ((uintptr_t)fr.cfa_dev % 4u) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f); break; }
         if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f); break; }
-        const rd_ku u = rd_make_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level,
-                                   b->math_mode);
+        if (fr.matrix_layout != RD_MATRIX_REFERENCE && fr.matrix_layout != RD_MATRIX_ROW_MAJOR) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: unknown matrix layout %u", f, fr.matrix_layout); break; }
+        const rd_ku u = rd_frame_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level,
+                                    b->math_mode, fr.matrix_layout);
         for (uint32_t k = 0; k < bands && rc == RD_OK; ++k, ++launch) {
             const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
             const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
@@ -1224,7 +1250,8 @@ extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *
     if (s.busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u has not been released (ring of %u full)", si, e->n_slots);
     // the previous copy out of this HBM slot must have finished before the kernel overwrites it
     if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
-    const rd_ku u = rd_make_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode);
+    if (fr->matrix_layout != RD_MATRIX_REFERENCE && fr->matrix_layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", fr->matrix_layout);
+    const rd_ku u = rd_frame_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode, fr->matrix_layout);
     const rd_scratch::lease l = e->scratch.get(e->compute, false);
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,

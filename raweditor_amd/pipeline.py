@@ -98,6 +98,10 @@ class RenderPipeline:
     def set_black_level(self, black_level: int) -> None:
         check(_lib.lib().rd_pipeline_set_black_level(self._h, int(black_level)))
 
+    def set_matrix_layout(self, layout: int) -> None:
+        """MATRIX_REFERENCE (default: rows consumed as columns, shaders.rs:209-214) or MATRIX_ROW_MAJOR (out = M c)."""
+        check(_lib.lib().rd_pipeline_set_matrix_layout(self._h, int(layout)))
+
     def set_math_mode(self, math_mode: int) -> None:
         """MATH_STRICT (default, literal WGSL order) or MATH_CONTRACTED (fma + reciprocal multiply)."""
         check(_lib.lib().rd_pipeline_set_math_mode(self._h, int(math_mode)))

@@ -424,3 +424,37 @@ def test_full_size_100mp_f16_row_bands(gpu_lib, refc):
     assert np.array_equal(d_out.to_array(np.uint16, (h, w, 4)), got)
     assert np.array_equal(d_hist.to_array(np.uint64, (768,)), hist)
     be.close()
+
+
+def test_matrix_layout_option(gpu_lib, refc, rng):
+    """rd_options.matrix_layout of SURVEY.md section 8b: the default consumes the host's rows as COLUMNS like the reference
+    (shaders.rs:209-214, quirk D4); RD_MATRIX_ROW_MAJOR applies the matrix as written.  Row-major with M must equal the
+    reference layout with M^T bit for bit, on the pipeline and on the batch path, and must equal the oracle fed M^T."""
+    from tests.gpu_util import DevBuf, sync
+    ra = gpu_lib
+    h, w = 130, 256
+    cfa = random_cfa(rng, h, w)
+    params = dict(exposure=-1.0, contrast=3.0, saturation=20.0, vibrance=0.3, whites=1.1, blacks=0.02)   # nothing clips wholesale
+    m = CM_TEST
+    mt = tuple(m[3 * c + r] for r in range(3) for c in range(3))
+    exp_ref = oracle(refc, cfa, params, WB_DAYLIGHT, m)
+    exp_row = oracle(refc, cfa, params, WB_DAYLIGHT, mt)
+    assert not np.array_equal(exp_ref, exp_row)
+    pipe = make_pipe(ra, cfa, params, WB_DAYLIGHT, m)
+    assert np.array_equal(pipe.render().view(np.uint32), exp_ref.view(np.uint32))
+    pipe.set_matrix_layout(ra.MATRIX_ROW_MAJOR)
+    assert np.array_equal(pipe.render().view(np.uint32), exp_row.view(np.uint32))
+    with pytest.raises(ra.RawdevError):
+        pipe.set_matrix_layout(7)
+    d_in, d_out = DevBuf.from_array(cfa), [DevBuf(h * w * 16), DevBuf(h * w * 16)]
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, False)
+    fr = be.make_frames([d_in.ptr, d_in.ptr], [d_out[0].ptr, d_out[1].ptr], [ra.EditParams(**params)] * 2, WB_DAYLIGHT, m)
+    fr[1].matrix_layout = ra.MATRIX_ROW_MAJOR
+    be.develop(fr)
+    sync()
+    assert np.array_equal(d_out[0].to_array(np.float32, (h, w, 4)).view(np.uint32), exp_ref.view(np.uint32))
+    assert np.array_equal(d_out[1].to_array(np.float32, (h, w, 4)).view(np.uint32), exp_row.view(np.uint32))
+    fr[1].matrix_layout = 9
+    with pytest.raises(ra.RawdevError):
+        be.develop(fr)
+    be.close()

@@ -90,7 +90,24 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.RdEditParams) == 40
     assert C.sizeof(_lib.RdInfo) == 32
-    assert C.sizeof(_lib.RdFrame) == 8 + 8 + 40 + 16 + 36 + 4 + 0 or C.sizeof(_lib.RdFrame) % 8 == 0
+    # the C compiler's own view of include/rawdev.h: sizes and field offsets of every struct that crosses the ABI
+    import subprocess, tempfile
+    src = """#include <stddef.h>
+#include <stdio.h>
+#include "rawdev.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rd_edit_params), sizeof(rd_info), sizeof(rd_frame),
+           offsetof(rd_frame, cfa_dev), offsetof(rd_frame, out_dev), offsetof(rd_frame, params), offsetof(rd_frame, wb_multipliers),
+           offsetof(rd_frame, color_matrix), offsetof(rd_frame, black_level), offsetof(rd_frame, matrix_layout));
+    return 0;
+}"""
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "l.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "l"), os.path.join(td, "l.c")], check=True)
+        got = [int(x) for x in subprocess.run([os.path.join(td, "l")], capture_output=True, text=True, check=True).stdout.split()]
+    F = _lib.RdFrame
+    assert got == [C.sizeof(_lib.RdEditParams), C.sizeof(_lib.RdInfo), C.sizeof(F), F.cfa_dev.offset, F.out_dev.offset, F.params.offset,
+                   F.wb_multipliers.offset, F.color_matrix.offset, F.black_level.offset, F.matrix_layout.offset], got
     assert _lib.lib().rd_format_bytes_per_pixel(ra.FMT_RGBA_F32) == 16
     assert _lib.lib().rd_format_bytes_per_pixel(ra.FMT_RGBA_F16) == 8
     assert _lib.lib().rd_format_bytes_per_pixel(ra.FMT_RGBA_U8) == 4
