@@ -285,7 +285,7 @@ def main():
         pass
 
     if (W, H) == (6016, 4016):
-        cfg_label = "BASELINE configs[2]" if world == 1 else "BASELINE configs[3] (256 frames per GPU)"
+        cfg_label = "BASELINE configs[2]" if world == 1 else f"BASELINE configs[3] ({F} frames per GPU)"
     elif (W, H) == (11648, 8736):
         cfg_label = "BASELINE configs[4] shape (100 MP; per GPU)"
     else:
