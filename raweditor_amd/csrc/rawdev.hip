@@ -303,7 +303,7 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
 // Multi-frame launch (rd_develop_batch): descs_dev[0 .. nframes-1] are whole frames of W x H.
 template <int FMT, bool HIST, int MATH>
 static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, uint32_t W, uint32_t H, uint32_t blocks,
-                              bool burst_ok, uint32_t pf_thr_pct, unsigned long long *slab64, uint32_t *tq, hipStream_t s)
+                              bool burst_ok, unsigned long long *slab64, uint32_t *tq, hipStream_t s)
 {
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;
     const uint32_t tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;
@@ -315,25 +315,22 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
     const uint32_t tq_k = static_deal ? 0u : (blocks >= 16u && blocks % 16u == 0u) ? blocks / 4u : 1u;
     const uint32_t ndyn = ntiles > nwaves ? ntiles - nwaves : 0u;
     const uint32_t tq_tmax = tq_k ? (ndyn + tq_k - 1u) / tq_k : 0u;
-    // where a wave's load stage must stand in frame f - 1 for it to start the sweep of frame f, in tiles (RD_PF_THR is in
-    // thousandths of a frame's tiles): 1000 = "at its first tile of frame f itself" (the default), above = never
-    const uint32_t pf_thr = pf_thr_pct > 1000u ? 0xffffffffu : (uint32_t)(((uint64_t)tpf * pf_thr_pct) / 1000u);
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;
     const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && W % 128u == 0 && (uint64_t)(H / 2u + 1u) * W >= (1u << 19) &&
                        (burst_env < 0 || burst_env != 0);
     if constexpr (FMT == RD_FMT_RGBA_F32) {
         if (burst) {
             hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes,
-                               W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, pf_thr, slab64);
+                               W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64);
             return;
         }
     }
     if (W % 128u == 0)
         hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, true, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes,
-                           W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, pf_thr, slab64);
+                           W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64);
     else
         hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, false, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes,
-                           W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, pf_thr, slab64);
+                           W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64);
 }
 
 template <int FMT, bool HIST, int MATH>
@@ -694,7 +691,6 @@ struct rd_batch {
     // step), and only after the launches that read it have finished (`done`).
     bool persistent = true;
     uint32_t max_frames = 8;                   // RD_BATCH_MAX_FRAMES: frames per launch (default 8: DESIGN.md section 6)
-    uint32_t pf_thr_pct = 1000;                // RD_PF_THR: where the sweep of the next frame starts (thousandths of a frame's tiles)
     struct desc_buf {
         rd_frame_desc *dev = nullptr, *host = nullptr;
         size_t cap = 0, n = 0;
@@ -734,7 +730,6 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
         const char *pe = getenv("RD_BATCH_PERSISTENT");
         b->persistent = !(pe && *pe == '0') && b->n_streams == 1;
         b->max_frames = rd_env_u32("RD_BATCH_MAX_FRAMES", 8);
-        b->pf_thr_pct = rd_env_u32("RD_PF_THR", 1000);
     }
     hipError_t e = hipSuccess;
     for (int j = 0; j < 2 && e == hipSuccess && b->persistent; ++j)
@@ -865,7 +860,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
             if (clash) break;
         }
         RD_DISPATCH(rd_launch_batch_t, b->fmt, b->hist, b->math_mode, descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16,
-                    b->pf_thr_pct, b->slab64, tq, s);
+                    b->slab64, tq, s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "multi-frame launch failed: %s", hipGetErrorString(e));
         else b->last_launches += 1;

@@ -402,7 +402,7 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // One tile's results, packed the way its surface stores want them, carried in registers from the
 // iteration that computes them to the next one, which stores them.
 template <int FMT> struct rd_tile_out;
-template <> struct rd_tile_out<RD_FMT_RGBA_F32> { rd_rgb c1, c2, c3; };
+template <> struct rd_tile_out<RD_FMT_RGBA_F32> { };      // nothing: the f32 tile waits in the wave's LDS stage, not in registers
 template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
 template <> struct rd_tile_out<RD_FMT_RGBA_U8> { uint32_t v1, v2, v3; };
 template <> struct rd_tile_out<RD_FMT_RGB_U8> { uint32_t v1, v2, v3; };                   // 0x00bbggrr
@@ -434,7 +434,7 @@ __device__ __forceinline__ void
 rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, uint32_t W, uint32_t H, uint32_t unit0,
               uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
               const rd_ku &u_arg, uint32_t *slab32, unsigned long long *slab64,
-              const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t tpf, uint32_t tpf_magic, uint32_t pf_thr)
+              const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t tpf, uint32_t tpf_magic)
 {
     // Register budget: two workgroups per CU need <= 80 SGPRs AND <= 64 VGPRs per wave (RD_NUM_SGPR above).  The uniforms of
     // the front of the stack (white balance, temperature/tint, matrix) and of the levels divide (17 values) are therefore parked in VGPRs -- the asm
@@ -461,10 +461,18 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     };
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
-    __shared__ rd_f4 stage[(FMT == RD_FMT_RGBA_F32 || BURST) ? RD_BLOCK * 3 : 1];
+    __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
-    __shared__ rd_f4 pf_dump[(BURST && MULTI) ? 64 : 1];         // where the later frames' sweep lands (never read)
+    __shared__ rd_f4 pf_dump[BURST ? 64 : 1];                    // where the LDS-DMA sweeps land (never read)
     if (HIST) rd_hist_zero(lh);
+    if constexpr (FMT == RD_FMT_RGBA_F32) {
+        // The store stage holds [lane][c1, c2, c3] as RGBA; alpha is 1.0 for every pixel of every tile, so it is written
+        // here once and the tiles only ever write r, g, b (12 bytes) next to it: no per-tile assembly of {r, g, b, 1}
+        // register quadruples (15 v_mov per tile), a quarter fewer LDS bytes written.
+        float *sa = reinterpret_cast<float *>(stage + (size_t)(threadIdx.x >> 6) * 192u + (threadIdx.x & 63u) * 3u);
+        sa[3] = 1.0f; sa[7] = 1.0f; sa[11] = 1.0f;
+        __builtin_amdgcn_wave_barrier();
+    }
 #ifdef RD_PROBE
     const uint64_t probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t probe_tiles = 0;
@@ -556,12 +564,17 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         constexpr bool H16 = FMT == RD_FMT_RGBA_F16;                              // only binary16 values (+ codes) leave it
 #endif
 #ifdef RD_COLOUR_HOOK_HEADER
+        constexpr bool F32T = false;
+#else
+        constexpr bool F32T = FMT == RD_FMT_RGBA_F32;      // f32 surface: gamma, histogram and stage write triple by triple (below)
+#endif
+#ifdef RD_COLOUR_HOOK_HEADER
         const rd_rgb c1 = RD_COLOUR(u, C, A, B);
         const rd_rgb c2 = RD_COLOUR(u, C, D, A);
         const rd_rgb c3 = RD_COLOUR(u, C, D, B);
 #else
         float tr[3] = { C, C, C }, tg[3] = { A, D, D }, tb[3] = { B, A, B };       // row a: (C,A,B); row b: (C,D,A), (C,D,B)
-        rd_colour_n<3, MATH, !(Q8ONLY || H16)>(u, tr, tg, tb);
+        rd_colour_n<3, MATH, !(Q8ONLY || H16 || F32T)>(u, tr, tg, tb);
         const rd_rgb c1 = { tr[0], tg[0], tb[0] }, c2 = { tr[1], tg[1], tb[1] }, c3 = { tr[2], tg[2], tb[2] };
 #endif
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
@@ -581,18 +594,38 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             rd_f16_gamma<HIST>(c3.r, hr, q3r); rd_f16_gamma<HIST>(c3.g, hg, q3g); rd_f16_gamma<HIST>(c3.b, hb, q3b);
             hc0 = hr | (hg << 16); hc1 = hb | 0x3c000000u;
             if (HIST && valid && has_b) rd_hist_add(lh, copy, q3r, q3g, q3b, 1u);
+        } else if constexpr (F32T) {
+            // One triple at a time: pinned gamma, codes into the histogram, r g b into the wave-private store stage
+            // ([lane][c1, c2, c3]; the alphas are already there), so a finished triple holds no registers.  The stage still
+            // holds the PREVIOUS tile until store_tile has read it -- which the loop does before it computes this one, and
+            // a wave's LDS operations execute in order.
+            rd_f4 *st = stage + (size_t)wave * 192u;
+            const rd_rgb g1 = { rd_gamma_clamp(c1.r), rd_gamma_clamp(c1.g), rd_gamma_clamp(c1.b) };
+            if (HIST && valid && has_a) rd_hist_add(lh, copy, rd_q8(g1.r), rd_q8(g1.g), rd_q8(g1.b), 2u);
+            *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = g1;
+            const rd_rgb g2 = { rd_gamma_clamp(c2.r), rd_gamma_clamp(c2.g), rd_gamma_clamp(c2.b) };
+            if (HIST && valid && has_b) rd_hist_add(lh, copy, rd_q8(g2.r), rd_q8(g2.g), rd_q8(g2.b), 1u);
+            *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 1u]) = g2;
+            const rd_rgb g3 = { rd_gamma_clamp(c3.r), rd_gamma_clamp(c3.g), rd_gamma_clamp(c3.b) };
+            if (HIST && valid && has_b) rd_hist_add(lh, copy, rd_q8(g3.r), rd_q8(g3.g), rd_q8(g3.b), 1u);
+            *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = g3;
         } else if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
             q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
             q3r = rd_q8(c3.r); q3g = rd_q8(c3.g); q3b = rd_q8(c3.b);
         }
-        if (HIST && valid && !H16) {
+        if (HIST && valid && !H16 && !F32T) {
             if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
             if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
         }
         rd_tile_out<FMT> r;
         if constexpr (FMT == RD_FMT_RGBA_F32) {
-            r.c1 = c1; r.c2 = c2; r.c3 = c3;
+            if constexpr (!F32T) {                               // microbench stand-ins only: all three at the end
+                rd_f4 *st = stage + (size_t)wave * 192u;
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = c1;
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 1u]) = c2;
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = c3;
+            }
         } else if constexpr (FMT == RD_FMT_RGBA_F16 && H16) {
             r.a0 = ha0; r.a1 = ha1; r.b0 = hb0; r.b1 = hb1; r.c0 = hc0; r.c1 = hc1;
         } else if constexpr (FMT == RD_FMT_RGBA_F16) {
@@ -623,10 +656,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         const uint32_t q = tq * 64u + lane;
         const bool valid = FULL || q < qpr;
         if constexpr (FMT == RD_FMT_RGBA_F32) {
-            rd_f4 *st = stage + (size_t)wave * 192u;             // wave-private: [lane][c1,c2,c3]
-            st[lane * 3u + 0u] = rd_f4{ r.c1.r, r.c1.g, r.c1.b, 1.0f };
-            st[lane * 3u + 1u] = rd_f4{ r.c2.r, r.c2.g, r.c2.b, 1.0f };
-            st[lane * 3u + 2u] = rd_f4{ r.c3.r, r.c3.g, r.c3.b, 1.0f };
+            (void)r;
+            const rd_f4 *st = stage + (size_t)wave * 192u;       // written by compute_tile
             __builtin_amdgcn_wave_barrier();
             RD_GLOBAL rd_f4 *o = reinterpret_cast<RD_GLOBAL rd_f4 *>(out);
 #pragma unroll
@@ -706,8 +737,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             // write streams: every isolated read costs the DRAM channel a write->read->write turnaround
             // (measured: the same bytes take 85-88 us mixed but 65 us when the CFA plane is already in the
             // Infinity Cache).  So before anything is stored the grid sweeps this launch's CFA rows once,
-            // 16 B per lane, fire-and-forget: LDS-DMA loads (global_load_lds_dwordx4) into this wave's
-            // not-yet-used store stage, so no VGPR is tied up and nothing waits for the data.  The whole
+            // 16 B per lane, fire-and-forget: LDS-DMA loads (global_load_lds_dwordx4) into a 1-KiB dump area
+            // nobody reads, so no VGPR is tied up and nothing waits for the data.  The whole
             // chip is in this phase together (persistent grid, nothing stored yet); the 48 MB land in the
             // 256 MiB Infinity Cache in one pure-read burst while every wave computes its first tile, and
             // the main loop's loads are served on-die.  nt stores do not displace the lines (measured).
@@ -743,8 +774,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 const uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
                 const RD_GLOBAL uint32_t *pt = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W) + q;
                 const RD_GLOBAL uint32_t *pb = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)rb * W) + q;
-                const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
-                    (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&stage[0]) + wave * (192u * 16u));
+                const uint32_t lds_base = __builtin_amdgcn_readfirstlane(          // every wave dumps into the same 1 KiB
+                    (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&pf_dump[0]));
                 const RD_GLOBAL rd_u4 *a[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -790,9 +821,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         // bookkeeping; they retire in order with the tile loads issued just after them, long before the compute
         // stage that follows has finished.  Measured (tools/bench_batch_ab.py, 8 frames per launch): 79.4 us per
         // frame with the sweep at frame entry, 84.1 us without any sweep of the later frames; starting the sweep
-        // earlier (pf_thr = 90 ... 99 % of the PREVIOUS frame's tiles) is no better (79.3 ... 80.1), much earlier
-        // (50 ... 75 %) is worse: the sweep then holds back the stores of the tiles in flight.
-        uint32_t pf_next = 1u;                                   // first frame not yet requested by this wave
+        // earlier (when the load stage stands at 90 ... 99 % of the PREVIOUS frame's tiles) was no better
+        // (79.3 ... 80.1), much earlier (50 ... 75 %) worse: the sweep then holds back the stores of the tiles in
+        // flight.  The threshold variant is gone; "at frame entry" is what remains.
         auto prefetch_frame = [&](uint32_t fr) {
             const char *base = reinterpret_cast<const char *>(descs[fr].cfa);
             const uint32_t n1k = (uint32_t)(((size_t)H * W * sizeof(uint16_t)) >> 10);   // whole 1-KiB pieces of a plane
@@ -821,15 +852,11 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             if (more) {
                 uint32_t f, tin;
                 locate(ntile, f, tin, nunit, nqt);
-                if (MULTI) {
-                    if (f != fr_n) { fr_n = f; cfa = (const RD_GLOBAL uint16_t *)descs[f].cfa; }
-                    if (BURST && pf_thr != ~0u) {            // ~0u: later frames are not swept (A/B)
-                        const uint32_t want = f + (tin >= pf_thr ? 1u : 0u);     // newest frame whose window has opened
-                        if (want >= pf_next) {
-                            pf_next = want + 1u;
-                            if (want < nframes) prefetch_frame(want);
-                        }
-                    }
+                (void)tin;
+                if (MULTI && f != fr_n) {                    // the load stage enters another frame
+                    fr_n = f;
+                    cfa = (const RD_GLOBAL uint16_t *)descs[f].cfa;
+                    if (BURST) prefetch_frame(f);            // this wave's share of the frame's sweep
                 }
             }
         };
@@ -884,7 +911,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
                  uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
 {
     rd_quads_body<FMT, HIST, FULL, MATH, BURST, false>(cfa, out, W, H, unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u_arg,
-                                                       slab32, slab64, nullptr, 1u, 0u, 0u, 0u);
+                                                       slab32, slab64, nullptr, 1u, 0u, 0u);
 }
 
 // `nframes` whole frames of one size per launch (descs[0 .. nframes-1], frame-major tile index; tpf = tiles per
@@ -894,10 +921,10 @@ template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST =
 __global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
 rd_develop_batch(const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t W, uint32_t H, uint32_t tpu,
                  uint32_t tpu_magic, uint32_t tpf, uint32_t tpf_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
-                 uint32_t pf_thr, unsigned long long *slab64)
+                 unsigned long long *slab64)
 {
     rd_quads_body<FMT, HIST, FULL, MATH, BURST, true>(nullptr, nullptr, W, H, 0u, H / 2u + 1u, tpu, tpu_magic, tq_k, tq_tmax, tq,
-                                                      descs[0].u, nullptr, slab64, descs, nframes, tpf, tpf_magic, pf_thr);
+                                                      descs[0].u, nullptr, slab64, descs, nframes, tpf, tpf_magic);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,11 +33,6 @@ VARIANTS = {
     "multi_r32_cap12": ({"RD_BATCH_MAX_FRAMES": "12"}, 32),
     "multi_r32_cap16": ({"RD_BATCH_MAX_FRAMES": "16"}, 32),
     "multi_r32_cap32": ({"RD_BATCH_MAX_FRAMES": "32"}, 32),
-    "multi_r8_nosweep": ({"RD_PF_THR": "1001"}, 8),
-    "multi_r8_thr990": ({"RD_PF_THR": "990"}, 8),
-    "multi_r8_thr970": ({"RD_PF_THR": "970"}, 8),
-    "multi_r8_thr900": ({"RD_PF_THR": "900"}, 8),
-    "multi_r32_cap32_thr970": ({"RD_BATCH_MAX_FRAMES": "32", "RD_PF_THR": "970"}, 32),
 }
 
 
