@@ -182,7 +182,8 @@ void rd_batch_destroy(rd_batch *b);
 int rd_batch_set_math_mode(rd_batch *b, uint32_t math_mode); /* rd_math_mode, default RD_MATH_STRICT */
 /* Enqueue the fused demosaic+develop(+histogram) of `n_frames` frames on `stream`, full resolution, zoom 1 / pan 0
  * (the export map).  Histogram counts accumulate inside the context in u64.  Not synchronised.
- * Launches: by default ONE launch covers several consecutive frames of the call (up to 8, RD_BATCH_MAX_FRAMES; the
+ * Launches: by default ONE launch covers several consecutive frames of the call (up to 8 for the f32 surface, 32 for the
+ * narrower ones; RD_BATCH_MAX_FRAMES; the
  * kernel's tile tickets, uniforms and surface pointers change frame inside the launch, so there is no drain / refill
  * between frames).  A launch never holds two frames whose surfaces overlap, so the surfaces of one call are always
  * written in call order where they alias (an output ring).  The frame array is copied before the call returns.

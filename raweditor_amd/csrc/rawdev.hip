@@ -690,7 +690,7 @@ struct rd_batch {
     // rewritten only when the caller's frames differ from what it holds (bench.py re-submits the same batch every
     // step), and only after the launches that read it have finished (`done`).
     bool persistent = true;
-    uint32_t max_frames = 8;                   // RD_BATCH_MAX_FRAMES: frames per launch (default 8: DESIGN.md section 6)
+    uint32_t max_frames = 8;                   // RD_BATCH_MAX_FRAMES: frames per launch (default 8 for f32, 32 otherwise)
     struct desc_buf {
         rd_frame_desc *dev = nullptr, *host = nullptr;
         size_t cap = 0, n = 0;
@@ -729,7 +729,9 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     {
         const char *pe = getenv("RD_BATCH_PERSISTENT");
         b->persistent = !(pe && *pe == '0') && b->n_streams == 1;
-        b->max_frames = rd_env_u32("RD_BATCH_MAX_FRAMES", 8);
+        // f32: 8 is the flat bottom of the curve; the narrow surfaces are arithmetic-bound and only
+        // lose launch tails as launches grow (u8 48.7 / 48.6 / 48.2, f16 61.2 / 60.6 / 60.2 us per frame at 8 / 16 / 32)
+        b->max_frames = rd_env_u32("RD_BATCH_MAX_FRAMES", fmt == RD_FMT_RGBA_F32 ? 8u : 32u);
     }
     hipError_t e = hipSuccess;
     for (int j = 0; j < 2 && e == hipSuccess && b->persistent; ++j)
