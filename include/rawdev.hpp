@@ -196,4 +196,51 @@ private:
     rd_pipeline *h_ = nullptr;
 };
 
+// A buffer in one device's HBM (rd_device_malloc / rd_device_free), for hosts without a HIP binding.
+class DeviceBuffer {
+public:
+    DeviceBuffer(int device, size_t bytes) : device_(device), bytes_(bytes) { check(rd_device_malloc(device, bytes, &p_)); }
+    DeviceBuffer(int device, const void *src, size_t bytes) : DeviceBuffer(device, bytes) { check(rd_memcpy_h2d(device, p_, src, bytes)); }
+    DeviceBuffer(DeviceBuffer &&o) noexcept : device_(o.device_), bytes_(o.bytes_), p_(o.p_) { o.p_ = nullptr; }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { if (p_) rd_device_free(device_, p_); }
+    void *get() const { return p_; }
+    size_t size() const { return bytes_; }
+    void download(void *dst, size_t bytes) const { check(rd_memcpy_d2h(device_, dst, p_, bytes)); }
+
+private:
+    int device_;
+    size_t bytes_;
+    void *p_ = nullptr;
+};
+
+// Batch export over the GPUs of one node from one process (rd_node_batch_*; no reference counterpart -- the reference exports
+// one frame per click, main.rs:1744-1799).  Frame i of a call belongs to devices[i mod N]; the global histogram is one RCCL
+// all-reduce of 768 x u64.
+class NodeBatch {
+public:
+    NodeBatch(const std::vector<int> &devices, uint32_t width, uint32_t height, rd_format format, bool with_histogram = true)
+        : devices_(devices)
+    {
+        check(rd_node_batch_create(devices.data(), (uint32_t)devices.size(), width, height, format, with_histogram ? 1u : 0u, &h_));
+    }
+    NodeBatch(const NodeBatch &) = delete;
+    NodeBatch &operator=(const NodeBatch &) = delete;
+    ~NodeBatch() { rd_node_batch_destroy(h_); }
+    int device_of(size_t frame_index) const { return devices_[rd_node_batch_device_of((uint32_t)devices_.size(), frame_index)]; }
+    void develop(const std::vector<rd_frame> &frames, uint32_t row_bands = 1) { check(rd_node_batch_develop(h_, frames.data(), frames.size(), row_bands)); }
+    std::array<std::array<uint64_t, 256>, 3> histogram()
+    {
+        std::array<std::array<uint64_t, 256>, 3> h;
+        check(rd_node_batch_histogram(h_, &h[0][0]));
+        return h;
+    }
+    void synchronize() { check(rd_node_batch_synchronize(h_)); }
+
+private:
+    std::vector<int> devices_;
+    rd_node_batch *h_ = nullptr;
+};
+
 }  // namespace rawdev

@@ -126,6 +126,58 @@ static void test_pipeline_gpu()
     EXPECT(from_thread == exp8 && here == exp8);
 }
 
+// The node-level batch entry through the C++ mirror: 5 frames on one device, surfaces and u64 histogram against the oracle.
+static void test_node_batch_gpu()
+{
+    const uint32_t w = 256, h = 66, n = 5;
+    const std::array<float, 4> wb = { 2.0f, 1.0f, 1.5f, 1.0f };
+    const std::array<float, 9> cm = { 1.6f, -0.4f, -0.2f, -0.3f, 1.5f, -0.2f, 0.0f, -0.5f, 1.5f };
+    rawdev::NodeBatch nb({ 0 }, w, h, RD_FMT_RGBA_F32, true);
+    std::vector<std::vector<uint16_t>> cfas(n, std::vector<uint16_t>((size_t)w * h));
+    std::vector<rawdev::DeviceBuffer> in, out;
+    std::vector<rd_frame> frames(n);
+    std::vector<std::vector<float>> exp(n, std::vector<float>((size_t)w * h * 4));
+    uint64_t ref_total[768] = { 0 };
+    uint64_t s = 99;
+    for (uint32_t i = 0; i < n; ++i) {
+        for (auto &v : cfas[i]) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (uint16_t)((s >> 40) & 4095u); }
+        rawdev::EditParams p;
+        p.exposure = 0.25f * (float)i - 0.5f; p.contrast = 2.0f * (float)i; p.saturation = 10.0f * (float)i; p.blacks = 0.01f * (float)i;
+        EXPECT(nb.device_of(i) == 0);
+        in.emplace_back(0, cfas[i].data(), cfas[i].size() * 2);
+        out.emplace_back(0, (size_t)w * h * 16);
+        std::memset(&frames[i], 0, sizeof(rd_frame));
+        frames[i].cfa_dev = (const uint16_t *)in[i].get();
+        frames[i].out_dev = out[i].get();
+        frames[i].params = p;
+        std::memcpy(frames[i].wb_multipliers, wb.data(), sizeof wb);
+        std::memcpy(frames[i].color_matrix, cm.data(), sizeof cm);
+        ref_uniforms u;
+        std::memset(&u, 0, sizeof u);
+        std::memcpy(&u.p, &p, sizeof u.p);
+        std::memcpy(u.wb, wb.data(), sizeof u.wb);
+        std::memcpy(u.cm, cm.data(), sizeof u.cm);
+        u.zoom = 1.0f;
+        ref_render_f32(cfas[i].data(), w, h, &u, w, h, REF_POW_PINNED, exp[i].data());
+        std::vector<uint8_t> e8(exp[i].size());
+        ref_pack_u8(exp[i].data(), exp[i].size(), e8.data());
+        uint32_t rh[768];
+        ref_histogram(e8.data(), (size_t)w * h, rh);
+        for (int k = 0; k < 768; ++k) ref_total[k] += rh[k];
+    }
+    nb.develop(frames);
+    const auto hist = nb.histogram();
+    EXPECT(std::memcmp(&hist[0][0], ref_total, sizeof ref_total) == 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::vector<float> got((size_t)w * h * 4);
+        out[i].download(got.data(), got.size() * sizeof(float));
+        EXPECT(std::memcmp(got.data(), exp[i].data(), got.size() * sizeof(float)) == 0);
+    }
+    bool threw = false;
+    try { rawdev::NodeBatch bad({ 0, 0 }, w, h, RD_FMT_RGBA_F32); } catch (const rawdev::Error &e) { threw = true; EXPECT(e.code == RD_ERR_INVALID_ARG); }
+    EXPECT(threw);                                         // a device listed twice needs RD_NODE_REDUCE=host
+}
+
 int main(int argc, char **argv)
 {
     const bool gpu = argc > 1 && std::string(argv[1]) == "--gpu";
@@ -136,6 +188,7 @@ int main(int argc, char **argv)
     test_color_stub();
     if (gpu) {
         test_pipeline_gpu();
+        test_node_batch_gpu();
     } else {
         int n = 0;
         if (rd_device_count(&n) != RD_OK || n == 0) {     // no CPU fallback: construction must fail loudly
