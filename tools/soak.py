@@ -1,4 +1,5 @@
-"""Soak test of the ticket-scheduled export kernel: tens of thousands of back-to-back launches on one batch context;
+"""Soak test of the ticket-scheduled export kernel: tens of thousands of frames back to back on one batch context
+(multi-frame launches by default; RD_BATCH_PERSISTENT=0 for one launch per frame / row band);
 every tile of every launch must be processed exactly once, which the accumulated u64 histogram shows (it must be
 exactly reps x the histogram of one pass) together with the bytes of the last pass (equal to the first pass)."""
 import os
@@ -41,8 +42,10 @@ def main():
         hn = hist.to_array(np.uint64, (768,))
         ok_h = np.array_equal(hn, h1 * np.uint64(REPS))
         ok_b = all(np.array_equal(o.to_array(np.uint8, (H * W * bpp,)), f) for o, f in zip(outs[:2], first))
-        print(f"{name}: {REPS * NF * bands} launches in {dt:.2f} s ({dt / (REPS * NF * bands) * 1e6:.1f} us each): "
-              f"histogram {'exact' if ok_h else 'MISMATCH'}, surfaces {'identical' if ok_b else 'DIFFER'}", flush=True)
+        lpc = be.last_launch_count()
+        print(f"{name}: {REPS} passes over {NF} frames = {REPS * NF} frames in {REPS * lpc} launches ({lpc} per pass), {dt:.2f} s "
+              f"({dt / (REPS * NF) * 1e6:.1f} us per frame): histogram {'exact' if ok_h else 'MISMATCH'}, "
+              f"surfaces {'identical' if ok_b else 'DIFFER'}", flush=True)
         be.close()
         if not (ok_h and ok_b):
             return 1
