@@ -371,9 +371,11 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 //
 // Stores: a lane's two f32 pixels are 32 B, so storing them directly gives every store
 // instruction a 32-B lane stride (half-used 64-B requests; measured 2.4 TB/s when store-bound).
-// The f32 surface therefore goes through a wave-private LDS transpose (3 ds_write_b128 +
-// 4 ds_read_b128 per lane) so that every global_store_dwordx4 writes 1 KiB contiguous.  f16
-// (16 B per lane per row) and u8 (8 B) are contiguous as they are and skip the transpose.
+// The f32 surface therefore goes through a wave-private LDS transpose (3 ds_write_b96 +
+// 4 ds_read_b128 per lane; the alpha words of the stage are written once per kernel) so that every
+// global_store_dwordx4 writes 1 KiB contiguous; the tile also WAITS there for its stores, one
+// iteration long, instead of in registers.  f16 (16 B per lane per row) and u8 (8 B) are contiguous
+// as they are, skip the transpose and carry their packed tile in registers.
 // ---------------------------------------------------------------------------------------------
 #define RD_WAVES (RD_BLOCK / 64)
 #define RD_TQ_STRIDE 32u        // dwords between ticket counters (128 B: one counter per cache line)
@@ -400,7 +402,8 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // not exist) is handled by redirecting that row's store onto the other row with the other row's
 // value -- a duplicate store of correct data -- instead of branching around it.
 // One tile's results, packed the way its surface stores want them, carried in registers from the
-// iteration that computes them to the next one, which stores them.
+// iteration that computes them to the next one, which stores them (f16 / u8 / rgb8; the f32 tile waits
+// in the LDS stage).
 template <int FMT> struct rd_tile_out;
 template <> struct rd_tile_out<RD_FMT_RGBA_F32> { };      // nothing: the f32 tile waits in the wave's LDS stage, not in registers
 template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
@@ -438,8 +441,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 {
     // Register budget: two workgroups per CU need <= 80 SGPRs AND <= 64 VGPRs per wave (RD_NUM_SGPR above).  The uniforms of
     // the front of the stack (white balance, temperature/tint, matrix) and of the levels divide (17 values) are therefore parked in VGPRs -- the asm
-    // keeps the compiler from folding them back into scalar operands -- which leaves the kernel at ~62 SGPRs / ~60 VGPRs
-    // with no spill.  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
+    // keeps the compiler from folding them back into scalar operands -- which leaves every instance at <= 78 SGPRs / <= 63 VGPRs
+    // (raweditor_amd/kernel_resources.json; the build fails beyond the budget).  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
     // that is not what limits this kernel: DESIGN.md section 6.)
     rd_ku u;
     auto adopt = [&](const rd_ku &src_mem) {                     // take over one frame's uniforms (MULTI: on every frame change)
