@@ -722,6 +722,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     b->device = device; b->w = w; b->h = h; b->fmt = fmt; b->hist = with_histogram != 0;
     b->cfg.n_cu = n_cu;
     b->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
+    b->cfg.wg_per_cu_hist = rd_env_u32("RD_WG_PER_CU_HIST", 2);      // experiment builds with a smaller RD_BLOCK only
     b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
     if (!b->identity_ok) { delete b; return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h); }
     b->blocks = rd_blocks_for(b->cfg, items, b->hist);
