@@ -171,6 +171,9 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # RCCL / device-tensor sharing across processes needs dmabuf IPC on this pool's host driver (already exported by the
+    # image; kept here so that a bare `python -m torch.distributed.run ... bench.py` works from any shell)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
