@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-alt-math", action="store_true",
                     help="skip the short extra run in the other math mode (reported under 'alt_math', N=1 only)")
     ap.add_argument("--no-hist", action="store_true")
+    ap.add_argument("--data", choices=["uniform", "gradient"], default="uniform",
+                    help="uniform: i.i.d. 12-bit samples (SURVEY 8d, the headline); gradient: smooth ramp + 1 %% noise "
+                         "(SURVEY 8d's second distribution: flat regions, same-bin histogram atomics, less bit toggling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     return ap.parse_args()
@@ -205,7 +208,16 @@ def main():
         gidx = rank + f * world                           # frame i -> rank i mod N
         g = torch.Generator(device=dev)
         g.manual_seed(SEED + gidx)
-        cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
+        if args.data == "uniform":
+            cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
+        else:                                             # a diagonal ramp whose slope and offset vary per frame, +-1 % noise
+            yy = torch.arange(H, device=dev, dtype=torch.float32)[:, None] / H
+            xx = torch.arange(W, device=dev, dtype=torch.float32)[None, :] / W
+            a = 0.25 + 0.5 * ((gidx * 37) % 16) / 16.0
+            ramp = (a * xx + (1.0 - a) * yy) * 3600.0 + 200.0
+            noise = (torch.rand((H, W), generator=g, device=dev) - 0.5) * 2.0 * 40.96
+            cfas.append((ramp + noise).clamp_(0, 4095).to(torch.int16))
+            del yy, xx, ramp, noise
         params.append(ra.EditParams.random(np.random.default_rng([SEED, gidx])))
     ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
@@ -305,7 +317,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",                                    # the arithmetic type of the path for EVERY surface format
-        "data": "synthetic",
+        "data": "synthetic" if args.data == "uniform" else "synthetic (gradient + 1 % noise)",
         "verified": verified,
         "verified_note": verified_note,
         "config": {
