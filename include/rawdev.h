@@ -193,6 +193,14 @@ int rd_batch_set_math_mode(rd_batch *b, uint32_t math_mode); /* rd_math_mode, de
  * per frame), as in ABI version 1. */
 int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n_frames, uint32_t row_bands,
                      void *stream);
+/* No device needed: how rd_batch_develop would cut `n_frames` frames of this size / format into multi-frame launches
+ * (`max_frames` = 0: the default cap, 8 for the f32 surface and 32 otherwise).  Writes the frames per launch, in order,
+ * into counts[0 .. counts_cap) (nullable) and returns the number of launches (or a negative rd_status).  The limits: a
+ * launch holds no two frames whose surfaces overlap, at most 2^32 - 1 pixels when a histogram is fused (u32 bins per
+ * workgroup), at most 2^32 - 2 tiles. */
+int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t format, uint32_t with_histogram,
+                           const rd_frame *frames, size_t n_frames, uint32_t max_frames, uint32_t *counts,
+                           size_t counts_cap);
 /* Number of fused kernel launches the last rd_batch_develop call on this context enqueued (measurement aid). */
 uint32_t rd_batch_last_launch_count(const rd_batch *b);
 /* Reduce the accumulated histogram into `hist_dev` (768 x u64 on the device: R[256] G[256] B[256])

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "rd_batch_destroy": (None, [_VP]),
     "rd_batch_set_math_mode": (_I, [_VP, _U32]),
     "rd_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32, _VP]),
+    "rd_batch_plan_launches": (_I, [_U32, _U32, _U32, _U32, C.POINTER(RdFrame), _SZ, _U32, C.POINTER(_U32), _SZ]),
     "rd_batch_last_launch_count": (_U32, [_VP]),
     "rd_batch_histogram": (_I, [_VP, _VP, _VP]),
     "rd_node_batch_create": (_I, [C.POINTER(_I), _U32, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),

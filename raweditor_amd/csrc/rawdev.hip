@@ -784,6 +784,58 @@ extern "C" int rd_batch_set_math_mode(rd_batch *b, uint32_t mode)
     return RD_OK;
 }
 
+// How many frames one multi-frame launch may hold for frames of w x h: the 32-bit tile index, the u32 histogram bins a
+// workgroup keeps in LDS for the whole launch (every pixel of the launch could, in principle, land in one bin of one
+// workgroup), and the per-format default / RD_BATCH_MAX_FRAMES cap.
+static uint64_t rd_frames_per_launch_limit(uint32_t w, uint32_t h, bool hist, uint32_t cap)
+{
+    const uint32_t tpu = ((w >> 1) + 63u) / 64u;
+    const uint64_t tpf = (uint64_t)(h / 2u + 1u) * tpu;
+    uint64_t kmax = 0xfffffffeull / tpf;
+    if (hist) { const uint64_t k2 = 0xffffffffull / ((uint64_t)w * h); if (k2 < kmax) kmax = k2; }
+    if (kmax > 4096) kmax = 4096;
+    if (cap && cap < kmax) kmax = cap;
+    return kmax < 1 ? 1 : kmax;
+}
+
+// Frames of the next launch, starting at frame i0: as many consecutive frames as the limit allows whose surfaces
+// ([out, out + surf_bytes)) overlap none of the launch's earlier ones.
+static size_t rd_next_launch_size(const rd_frame *frames, size_t n, size_t i0, size_t surf_bytes, uint64_t kmax)
+{
+    size_t c = 1;
+    for (; i0 + c < n && c < kmax; ++c) {
+        const uintptr_t o = (uintptr_t)frames[i0 + c].out_dev;
+        bool clash = false;
+        for (size_t k = 0; k < c && !clash; ++k) {
+            const uintptr_t p = (uintptr_t)frames[i0 + k].out_dev;
+            clash = o < p + surf_bytes && p < o + surf_bytes;
+        }
+        if (clash) break;
+    }
+    return c;
+}
+
+// No device needed: the launches rd_batch_develop would cut a call into (frames per launch, in order).  Returns the number
+// of launches, or a negative rd_status; at most `counts_cap` entries are written.
+extern "C" int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t format, uint32_t with_histogram,
+                                      const rd_frame *frames, size_t n_frames, uint32_t max_frames, uint32_t *counts,
+                                      size_t counts_cap)
+{
+    const size_t bpp = rd_format_bytes_per_pixel(format);
+    if (!width || !height || !bpp || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "rd_batch_plan_launches: bad argument");
+    const uint32_t cap = max_frames ? max_frames : (format == RD_FMT_RGBA_F32 ? 8u : 32u);
+    const uint64_t kmax = rd_frames_per_launch_limit(width, height, with_histogram != 0, cap);
+    const size_t surf = (size_t)width * height * bpp;
+    int launches = 0;
+    for (size_t i0 = 0; i0 < n_frames;) {
+        const size_t c = rd_next_launch_size(frames, n_frames, i0, surf, kmax);
+        if (counts && (size_t)launches < counts_cap) counts[launches] = (uint32_t)c;
+        ++launches;
+        i0 += c;
+    }
+    return launches;
+}
+
 // The multi-frame path of rd_batch_develop: descriptors -> HBM (only when they changed), then as few launches as the
 // limits allow.  A launch never holds two frames whose surfaces overlap (the order in which the tiles of DIFFERENT frames
 // are stored inside one launch is not defined), never more pixels than a u32 histogram bin can count, and never more
@@ -838,13 +890,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     b->db_last = j;
     const rd_frame_desc *descs = b->db[j].dev;
 
-    const uint32_t tpu = ((b->w >> 1) + 63u) / 64u;
-    const uint64_t tpf = (uint64_t)(b->h / 2u + 1u) * tpu;
-    uint64_t kmax = 0xfffffffeull / tpf;                                   // 32-bit tile index
-    if (b->hist) { const uint64_t k2 = 0xffffffffull / ((uint64_t)b->w * b->h); if (k2 < kmax) kmax = k2; }   // u32 LDS bins
-    if (kmax > 4096) kmax = 4096;
-    if (b->max_frames && b->max_frames < kmax) kmax = b->max_frames;
-    if (kmax < 1) kmax = 1;
+    const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->hist, b->max_frames);
     const rd_scratch::lease l = b->scratch.get(s, false);
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     uint32_t *tq = l.tq;
@@ -852,16 +898,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     b->last_launches = 0;
     (void)hipGetLastError();                     // see rd_enqueue_render
     for (size_t i0 = 0; i0 < n && rc == RD_OK;) {
-        size_t c = 1;
-        for (; i0 + c < n && c < kmax; ++c) {                               // grow while the next surface overlaps none in the launch
-            const uintptr_t o = (uintptr_t)frames[i0 + c].out_dev;
-            bool clash = false;
-            for (size_t k = 0; k < c && !clash; ++k) {
-                const uintptr_t p = (uintptr_t)frames[i0 + k].out_dev;
-                clash = o < p + surf_bytes && p < o + surf_bytes;
-            }
-            if (clash) break;
-        }
+        const size_t c = rd_next_launch_size(frames, n, i0, surf_bytes, kmax);
         RD_DISPATCH(rd_launch_batch_t, b->fmt, b->hist, b->math_mode, descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16,
                     b->slab64, tq, s);
         hipError_t e = hipGetLastError();

@@ -241,3 +241,47 @@ def test_node_batch_dealing_rule_and_no_device():
         rc = L.rd_node_batch_create(devs, 2, 64, 64, ra.FMT_RGBA_F32, 1, C.byref(h))
         assert rc in (-2, -3) and not h.value, (rc, L.rd_last_error())
         assert L.rd_node_batch_develop(None, None, 0, 1) == -1
+
+
+def test_multi_frame_launch_planning():
+    """rd_batch_plan_launches (no device): how a call is cut into multi-frame launches.  A launch never holds two frames
+    whose surfaces overlap (an output ring of r surfaces caps it at r), never more pixels than a u32 histogram bin can
+    count, and at most the per-format default / the explicit cap."""
+    import ctypes as C
+    L = _lib.lib()
+
+    def plan(w, h, fmt, hist, outs, cap=0):
+        n = len(outs)
+        fr = (_lib.RdFrame * n)()
+        for i, o in enumerate(outs):
+            fr[i].cfa_dev = 0x1000
+            fr[i].out_dev = o
+        counts = (C.c_uint32 * 1024)()
+        k = L.rd_batch_plan_launches(w, h, fmt, 1 if hist else 0, fr, n, cap, counts, 1024)
+        assert k >= 0
+        return list(counts[:k])
+
+    W, H = 6016, 4016
+    surf = W * H * 16
+    base = 1 << 40
+    ring8 = [base + (i % 8) * surf for i in range(256)]
+    assert plan(W, H, ra.FMT_RGBA_F32, True, ring8) == [8] * 32                      # bench.py's default step
+    distinct = [base + i * surf for i in range(256)]
+    assert plan(W, H, ra.FMT_RGBA_F32, True, distinct) == [8] * 32                   # f32 default cap
+    assert plan(W, H, ra.FMT_RGBA_F32, True, distinct, cap=32) == [32] * 8
+    assert plan(W, H, ra.FMT_RGBA_F32, True, distinct, cap=1000) == [177, 79]         # 2^32 / 24 160 256 px = 177 with a histogram
+    assert plan(W, H, ra.FMT_RGBA_F32, False, distinct, cap=1000) == [256]            # without one: the tile index allows 45 000
+    surf8 = W * H * 4
+    d8 = [base + i * surf8 for i in range(100)]
+    assert plan(W, H, ra.FMT_RGBA_U8, True, d8) == [32, 32, 32, 4]                    # narrow surfaces default to 32
+    ring3 = [base + (i % 3) * surf8 for i in range(7)]
+    assert plan(W, H, ra.FMT_RGBA_U8, True, ring3) == [3, 3, 1]
+    # partial overlap counts as overlap; a surface one byte past the previous one's end does not
+    assert plan(W, H, ra.FMT_RGBA_U8, True, [base, base + surf8 - 4, base + 2 * surf8]) == [1, 2]
+    assert plan(W, H, ra.FMT_RGBA_U8, True, [base, base + surf8, base + 2 * surf8]) == [3]
+    # 100 MP frames with a histogram: 2^32 / 101 756 928 px = 42 frames at most
+    big = [base + i * 11648 * 8736 * 8 for i in range(64)]
+    assert plan(11648, 8736, ra.FMT_RGBA_F16, True, big, cap=1000) == [42, 22]
+    assert plan(11648, 8736, ra.FMT_RGBA_F16, True, big) == [32, 32]
+    assert plan(W, H, ra.FMT_RGBA_F32, True, []) == []
+    assert L.rd_batch_plan_launches(0, H, ra.FMT_RGBA_F32, 1, None, 0, 0, None, 0) == -1
