@@ -285,3 +285,14 @@ def test_multi_frame_launch_planning():
     assert plan(11648, 8736, ra.FMT_RGBA_F16, True, big) == [32, 32]
     assert plan(W, H, ra.FMT_RGBA_F32, True, []) == []
     assert L.rd_batch_plan_launches(0, H, ra.FMT_RGBA_F32, 1, None, 0, 0, None, 0) == -1
+
+
+def test_q8_pack_by_fma_is_the_pinned_pack_for_every_float_in_0_1(tmp_path):
+    """The kernels pack 8-bit codes as trunc(fma(x, 255, 0.5)); the pin (and the oracle) is trunc(RN(x*255) + 0.5).
+    tools/q8_fma_check.c compares the two for every float encoding in [0, 1] (about 2.5 s)."""
+    import subprocess
+    exe = tmp_path / "q8_fma_check"
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tools", "q8_fma_check.c"), "-lm", "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, check=True).stdout
+    assert out.startswith("mismatches 0 "), out
