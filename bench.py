@@ -367,6 +367,7 @@ def main():
         print(json.dumps(result), flush=True)
     be.close()
     if world > 1:
+        dist.barrier()                                     # rank 0 spent a second on the oracle check: leave together
         dist.destroy_process_group()
 
 
