@@ -13,7 +13,7 @@ exactly is everything loader.rs does AFTER the decode (src/raw/loader.rs:57-152)
     else identity (:115-134).
 
 Two containers are read: a headerless u16 plane (dimensions from the caller / the catalog row), and
-uncompressed 16-bit CFA DNG/TIFF (Compression = 1, one sample per pixel).  No pixel arithmetic happens
+uncompressed CFA DNG/TIFF (Compression = 1, one sample per pixel, 8 / 10 / 12 / 14 bits packed or 16 bits).  No pixel arithmetic happens
 here -- the samples go to HBM untouched.
 """
 from __future__ import annotations
@@ -67,6 +67,15 @@ def samples_to_u16(values: np.ndarray) -> np.ndarray:
         v = np.nan_to_num(v, nan=0.0, posinf=65535.0, neginf=0.0)     # Rust's saturating `as u16`: NaN -> 0
         return np.clip(v, np.float32(0.0), np.float32(65535.0)).astype(np.uint16)
     return values.astype(np.uint16, copy=False)
+
+
+def unpack_bits(rows: np.ndarray, width: int, bits: int) -> np.ndarray:
+    """(n_rows, row_bytes) uint8, samples of `bits` bits packed MSB first -> (n_rows, width) uint16."""
+    if bits == 8:
+        return rows[:, :width].astype(np.uint16)
+    b = np.unpackbits(rows, axis=1)[:, :width * bits].reshape(rows.shape[0], width, bits)
+    weights = (1 << np.arange(bits - 1, -1, -1)).astype(np.uint32)
+    return (b.astype(np.uint32) * weights).sum(axis=2).astype(np.uint16)
 
 
 def load_raw_u16(path: str, width: int, height: int, wb_coeffs: Sequence[float] = (),
@@ -128,7 +137,7 @@ def _read_ifd(buf: bytes, off: int, e: str):
 
 
 def load_dng_uncompressed(path: str) -> RawDataResult:
-    """Uncompressed (Compression = 1) 16-bit single-sample CFA image from a DNG/TIFF; anything else is an error."""
+    """Uncompressed (Compression = 1) single-sample CFA image (8 ... 16 bits) from a DNG/TIFF; anything else is an error."""
     if not os.path.exists(path):
         raise FileNotFoundError(f"File not found: {path}")
     with open(path, "rb") as fh:
@@ -159,8 +168,9 @@ def load_dng_uncompressed(path: str) -> RawDataResult:
     raw = next((t for t in ifds if t.get(TAG_PHOTOMETRIC, [None])[0] == PHOTOMETRIC_CFA), None)
     if raw is None:
         raise ValueError("Failed to decode RAW: no CFA image in the file")
-    if raw.get(TAG_COMPRESSION, [1])[0] != 1 or raw.get(TAG_BITS, [0])[0] != 16 or raw.get(TAG_SPP, [1])[0] != 1:
-        raise ValueError("Failed to decode RAW: only uncompressed 16-bit single-sample CFA data is supported")
+    bits = raw.get(TAG_BITS, [0])[0]
+    if raw.get(TAG_COMPRESSION, [1])[0] != 1 or bits not in (8, 10, 12, 14, 16) or raw.get(TAG_SPP, [1])[0] != 1:
+        raise ValueError("Failed to decode RAW: only uncompressed single-sample CFA data of 8, 10, 12, 14 or 16 bits is supported")
     for need in (TAG_WIDTH, TAG_LENGTH, TAG_STRIP_OFFSETS, TAG_STRIP_BYTES):
         if not raw.get(need):
             raise _decode_error(f"CFA image lacks tag {need}")
@@ -168,10 +178,20 @@ def load_dng_uncompressed(path: str) -> RawDataResult:
     if len(raw[TAG_STRIP_OFFSETS]) != len(raw[TAG_STRIP_BYTES]):
         raise _decode_error("StripOffsets and StripByteCounts differ in length")
     for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES]):
-        if o + nbytes > len(buf) or nbytes % 2:
+        if o + nbytes > len(buf) or (bits == 16 and nbytes % 2):
             raise _decode_error(f"strip ({nbytes} bytes at {o}) is outside the file or not whole samples")
-    parts = [np.frombuffer(buf, dtype=e + "u2", count=nbytes // 2, offset=o)
-             for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES])]
+    if bits == 16:
+        parts = [np.frombuffer(buf, dtype=e + "u2", count=nbytes // 2, offset=o)
+                 for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES])]
+    else:
+        # 8 / 10 / 12 / 14 bits: samples packed most-significant-bit first whatever the file's byte order (TIFF FillOrder 1,
+        # DNG spec "BitsPerSample"), every row starting on a byte boundary
+        row_bytes = (w * bits + 7) // 8
+        parts = []
+        for o, nbytes in zip(raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES]):
+            if nbytes % row_bytes:
+                raise _decode_error(f"strip of {nbytes} bytes is not whole rows of {row_bytes} bytes")
+            parts.append(unpack_bits(np.frombuffer(buf, dtype=np.uint8, count=nbytes, offset=o).reshape(-1, row_bytes), w, bits).reshape(-1))
     data = np.concatenate(parts).astype(np.uint16) if len(parts) > 1 else parts[0].astype(np.uint16)
     if data.size != w * h:
         raise ValueError(f"Failed to decode RAW: {data.size} samples for {w}x{h}")

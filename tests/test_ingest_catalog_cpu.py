@@ -73,13 +73,24 @@ def test_raw_u16_plane(tmp_path, rng):
         ingest.load_raw_u16(str(path), 15, 10)
 
 
-def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2):
+def _pack_rows(cfa, bits):
+    """samples of `bits` bits, MSB first, every row padded to a whole byte (TIFF FillOrder 1)"""
+    h, w = cfa.shape
+    b = ((cfa[:, :, None].astype(np.uint32) >> np.arange(bits - 1, -1, -1)) & 1).astype(np.uint8).reshape(h, w * bits)
+    return np.packbits(b, axis=1)                        # pads each row with zero bits
+
+
+def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2, bits=16):
     """A minimal uncompressed CFA DNG: IFD0 (thumbnail-less metadata) -> SubIFD with the raw strips."""
     h, w = cfa.shape
     e = endian
-    data = cfa.astype(e + "u2").tobytes()
     rows = (h + strips - 1) // strips
-    chunks = [data[i * rows * w * 2:(i + 1) * rows * w * 2] for i in range(strips)]
+    if bits == 16:
+        data, row_bytes = cfa.astype(e + "u2").tobytes(), w * 2
+    else:
+        packed = _pack_rows(cfa, bits)
+        data, row_bytes = packed.tobytes(), packed.shape[1]
+    chunks = [data[i * rows * row_bytes:(i + 1) * rows * row_bytes] for i in range(strips)]
     chunks = [c for c in chunks if c]
 
     def entry(tag, typ, vals, blob_off):
@@ -104,7 +115,7 @@ def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2):
     ifd0_entries = [(330, 4, [0]), (50728, 10, neutral_r), (50721, 10, cm)]
     ifd0_len = len(build_ifd(ifd0_entries, 8))
     sub_off = 8 + ifd0_len
-    sub_entries = [(256, 4, [w]), (257, 4, [h]), (258, 3, [16]), (259, 3, [1]), (262, 3, [32803]), (277, 3, [1]),
+    sub_entries = [(256, 4, [w]), (257, 4, [h]), (258, 3, [bits]), (259, 3, [1]), (262, 3, [32803]), (277, 3, [1]),
                    (278, 4, [rows]), (273, 4, [0] * len(chunks)), (279, 4, [len(c) for c in chunks])]
     sub_len = len(build_ifd(sub_entries, sub_off))
     data_off = sub_off + sub_len
@@ -192,3 +203,17 @@ def test_float_samples_and_json_edges():
     with pytest.raises(ValueError):
         EditParams.from_json(EditParams().to_json().replace('"contrast":0.0', '"contrast":true'))
     assert EditParams.from_json(EditParams().to_json().replace('"contrast":0.0', '"contrast":3')).contrast == 3.0
+
+
+@pytest.mark.parametrize("bits", [8, 10, 12, 14])
+@pytest.mark.parametrize("endian", ["<", ">"])
+def test_uncompressed_dng_with_packed_samples(tmp_path, rng, bits, endian):
+    """BitsPerSample 8 / 10 / 12 / 14: samples packed MSB first whatever the file's byte order, rows byte-aligned (an odd
+    width makes the padding real)."""
+    cfa = rng.integers(0, 1 << bits, (7, 13), dtype=np.uint16)
+    path = tmp_path / f"packed{bits}.dng"
+    _write_dng(path, cfa, endian, strips=3, bits=bits)
+    r = ingest.load_dng_uncompressed(str(path))
+    assert (r.width, r.height) == (13, 7) and r.data.dtype == np.uint16
+    assert np.array_equal(r.data.reshape(7, 13), cfa)
+    assert np.array_equal(ingest.unpack_bits(_pack_rows(cfa, bits), 13, bits), cfa)
