@@ -267,6 +267,14 @@ int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_
 int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks);
 int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst);
 
+/* ---- ingest helper (the step before the path; no device needed) ------------------ */
+/* Lossless JPEG (ITU-T T.81 SOF3: Huffman, predictors 1-7, 1-4 interleaved components, precision 2-16, restart
+ * intervals) as found in the tiles / strips of compressed DNGs (TIFF Compression = 7).  The reference decodes RAW files
+ * with the un-vendored `rawloader` crate (raw/loader.rs:50-54): no parity claim against it; lossless JPEG is exact by
+ * construction.  dst receives height * width * components samples, row-major, components interleaved. */
+int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_capacity_samples, uint32_t *width,
+                    uint32_t *height, uint32_t *components, uint32_t *precision);
+
 /* ---- plumbing for hosts without a HIP binding (tests, the Python mirror) -------------------- */
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);

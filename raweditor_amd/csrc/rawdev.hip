@@ -26,6 +26,7 @@
 
 #include "../../include/rawdev.h"
 #include "rd_kernels.h"
+#include "rd_ljpeg.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -1454,6 +1455,23 @@ extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_
     (void)hipFree(dev);
     if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_codes: %s", hipGetErrorString(e));
     return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest helper: lossless-JPEG tiles of compressed DNGs (host code; rd_ljpeg.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_capacity_samples, uint32_t *width,
+                               uint32_t *height, uint32_t *components, uint32_t *precision)
+{
+    if (!src || !dst) return rd_fail(RD_ERR_INVALID_ARG, "rd_ljpeg_decode: NULL argument");
+    const int rc = rd_ljpeg::decode(src, len, dst, dst_capacity_samples, width, height, components, precision);
+    switch (rc) {
+    case rd_ljpeg::OK: return RD_OK;
+    case rd_ljpeg::ERR_UNSUPPORTED: return rd_fail(RD_ERR_UNSUPPORTED, "Failed to decode RAW: not a Huffman-coded lossless JPEG this decoder supports");
+    case rd_ljpeg::ERR_SIZE: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: lossless-JPEG frame is larger than the destination");
+    case rd_ljpeg::ERR_TRUNCATED: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: lossless-JPEG stream is truncated");
+    default: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: malformed lossless-JPEG stream");
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

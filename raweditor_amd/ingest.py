@@ -95,7 +95,9 @@ _TYPE_SIZE = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 7: 1, 8: 2, 9: 4, 10: 8, 11: 4
 _TYPE_FMT = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 11: "f", 12: "d"}
 TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
 TAG_STRIP_OFFSETS, TAG_SPP, TAG_ROWS_PER_STRIP, TAG_STRIP_BYTES, TAG_SUBIFD = 273, 277, 278, 279, 330
+TAG_TILE_WIDTH, TAG_TILE_LENGTH, TAG_TILE_OFFSETS, TAG_TILE_BYTES = 322, 323, 324, 325
 TAG_COLOR_MATRIX1, TAG_AS_SHOT_NEUTRAL = 50721, 50728
+COMPRESSION_NONE, COMPRESSION_LJPEG = 1, 7
 PHOTOMETRIC_CFA = 32803
 
 
@@ -136,8 +138,41 @@ def _read_ifd(buf: bytes, off: int, e: str):
     return tags, nxt
 
 
+def ljpeg_decode(stream: bytes) -> np.ndarray:
+    """One lossless-JPEG stream (ITU-T T.81 SOF3) -> (height, width * components) uint16, through librawdev's host-side
+    decoder (rd_ljpeg_decode).  Errors carry the reference's "Failed to decode RAW" text."""
+    import ctypes as C
+    from . import _lib
+    buf = bytes(stream)
+    if len(buf) < 12 or buf[:2] != b"\xff\xd8":
+        raise _decode_error("not a JPEG stream")
+    # the frame header says how many samples to expect: find SOF3 (0xFFC3) cheaply for the allocation
+    i = buf.find(b"\xff\xc3")
+    if i < 0 or i + 10 > len(buf):
+        raise _decode_error("no lossless-JPEG frame header (SOF3)")
+    h, w, nc = struct.unpack_from(">HH", buf, i + 5) + (buf[i + 9],)
+    n = int(h) * int(w) * int(nc)
+    if n <= 0 or n > (1 << 31):
+        raise _decode_error("implausible lossless-JPEG frame size")
+    out = np.empty(n, np.uint16)
+    dims = [C.c_uint32() for _ in range(4)]
+    src = (C.c_uint8 * len(buf)).from_buffer_copy(buf)
+    rc = _lib.lib().rd_ljpeg_decode(src, len(buf), out.ctypes.data_as(C.c_void_p), n, *[C.byref(d) for d in dims])
+    if rc != 0:
+        raise ValueError(_lib.lib().rd_last_error().decode("utf-8", "replace"))
+    hh, ww = dims[1].value, dims[0].value * dims[2].value
+    return out[:hh * ww].reshape(hh, ww)
+
+
 def load_dng_uncompressed(path: str) -> RawDataResult:
     """Uncompressed (Compression = 1) single-sample CFA image (8 ... 16 bits) from a DNG/TIFF; anything else is an error."""
+    return load_dng(path, allow_compressed=False)
+
+
+def load_dng(path: str, allow_compressed: bool = True) -> RawDataResult:
+    """The CFA image of a DNG/TIFF: uncompressed strips (8 ... 16 bits), or lossless-JPEG strips / tiles (Compression = 7,
+    what Adobe's DNG converter and DNG-writing cameras produce).  The reference hands every RAW file to `rawloader`
+    (loader.rs:50-54); its source is absent, so there is no parity claim against it -- lossless JPEG decodes exactly."""
     if not os.path.exists(path):
         raise FileNotFoundError(f"File not found: {path}")
     with open(path, "rb") as fh:
@@ -169,8 +204,15 @@ def load_dng_uncompressed(path: str) -> RawDataResult:
     if raw is None:
         raise ValueError("Failed to decode RAW: no CFA image in the file")
     bits = raw.get(TAG_BITS, [0])[0]
-    if raw.get(TAG_COMPRESSION, [1])[0] != 1 or bits not in (8, 10, 12, 14, 16) or raw.get(TAG_SPP, [1])[0] != 1:
-        raise ValueError("Failed to decode RAW: only uncompressed single-sample CFA data of 8, 10, 12, 14 or 16 bits is supported")
+    compression = raw.get(TAG_COMPRESSION, [1])[0]
+    if raw.get(TAG_SPP, [1])[0] != 1:
+        raise _decode_error("only single-sample CFA data is supported")
+    if compression == COMPRESSION_LJPEG and allow_compressed:
+        data, w, h = _read_ljpeg_image(buf, raw)
+        return _finish(ifds, raw, data, w, h)
+    if compression != COMPRESSION_NONE or bits not in (8, 10, 12, 14, 16):
+        raise ValueError("Failed to decode RAW: only uncompressed single-sample CFA data of 8, 10, 12, 14 or 16 bits is supported"
+                         + (" (or lossless-JPEG compressed)" if allow_compressed else ""))
     for need in (TAG_WIDTH, TAG_LENGTH, TAG_STRIP_OFFSETS, TAG_STRIP_BYTES):
         if not raw.get(need):
             raise _decode_error(f"CFA image lacks tag {need}")
@@ -195,6 +237,54 @@ def load_dng_uncompressed(path: str) -> RawDataResult:
     data = np.concatenate(parts).astype(np.uint16) if len(parts) > 1 else parts[0].astype(np.uint16)
     if data.size != w * h:
         raise ValueError(f"Failed to decode RAW: {data.size} samples for {w}x{h}")
+    return _finish(ifds, raw, data, w, h)
+
+
+def _read_ljpeg_image(buf: bytes, raw: dict):
+    """Compression = 7: every strip or tile is one lossless-JPEG stream whose samples, read in stream order, are the
+    strip's / tile's CFA samples row by row (encoders commonly declare two components of half the width -- or two rows per
+    JPEG line -- to give the predictor same-colour neighbours; the sample order is unchanged by that)."""
+    for need in (TAG_WIDTH, TAG_LENGTH):
+        if not raw.get(need):
+            raise _decode_error(f"CFA image lacks tag {need}")
+    w, h = int(raw[TAG_WIDTH][0]), int(raw[TAG_LENGTH][0])
+    if w <= 0 or h <= 0 or w * h > (1 << 31):
+        raise _decode_error(f"implausible image size {w}x{h}")
+    if raw.get(TAG_TILE_OFFSETS):
+        for need in (TAG_TILE_WIDTH, TAG_TILE_LENGTH, TAG_TILE_BYTES):
+            if not raw.get(need):
+                raise _decode_error(f"tiled CFA image lacks tag {need}")
+        tw, th = int(raw[TAG_TILE_WIDTH][0]), int(raw[TAG_TILE_LENGTH][0])
+        offs, sizes = raw[TAG_TILE_OFFSETS], raw[TAG_TILE_BYTES]
+    else:
+        for need in (TAG_STRIP_OFFSETS, TAG_STRIP_BYTES):
+            if not raw.get(need):
+                raise _decode_error(f"CFA image lacks tag {need}")
+        tw, th = w, int(raw.get(TAG_ROWS_PER_STRIP, [h])[0]) or h
+        th = min(th, h)
+        offs, sizes = raw[TAG_STRIP_OFFSETS], raw[TAG_STRIP_BYTES]
+    if tw <= 0 or th <= 0:
+        raise _decode_error("bad tile / strip size")
+    across, down = (w + tw - 1) // tw, (h + th - 1) // th
+    if len(offs) != len(sizes) or len(offs) < across * down:
+        raise _decode_error(f"{len(offs)} tiles / strips for a {across}x{down} grid")
+    out = np.zeros((h, w), np.uint16)
+    for k in range(across * down):
+        o, nbytes = int(offs[k]), int(sizes[k])
+        if o + nbytes > len(buf) or nbytes < 4:
+            raise _decode_error(f"tile {k} ({nbytes} bytes at {o}) is outside the file")
+        tile = ljpeg_decode(buf[o:o + nbytes])
+        y0, x0 = (k // across) * th, (k % across) * tw
+        rows = min(th, h - y0) if not raw.get(TAG_TILE_OFFSETS) else th
+        if tile.size < rows * tw:
+            raise _decode_error(f"tile {k} holds {tile.size} samples, expected {rows * tw}")
+        tile = tile.reshape(-1)[:rows * tw].reshape(rows, tw)
+        hh, ww = min(rows, h - y0), min(tw, w - x0)
+        out[y0:y0 + hh, x0:x0 + ww] = tile[:hh, :ww]          # edge tiles are padded to the full tile size: crop
+    return out.reshape(-1), w, h
+
+
+def _finish(ifds, raw, data, w, h) -> RawDataResult:
     meta = ifds[0]
     neutral = meta.get(TAG_AS_SHOT_NEUTRAL) or raw.get(TAG_AS_SHOT_NEUTRAL)
     wb = [1.0 / x if x else 0.0 for x in neutral[:3]] if neutral else []      # multipliers = 1 / neutral

@@ -217,3 +217,170 @@ def test_uncompressed_dng_with_packed_samples(tmp_path, rng, bits, endian):
     assert (r.width, r.height) == (13, 7) and r.data.dtype == np.uint16
     assert np.array_equal(r.data.reshape(7, 13), cfa)
     assert np.array_equal(ingest.unpack_bits(_pack_rows(cfa, bits), 13, bits), cfa)
+
+
+# ---- lossless-JPEG compressed DNG (Compression = 7): librawdev's decoder against an independent encoder ------------------
+@pytest.mark.parametrize("predictor", [1, 2, 3, 4, 5, 6, 7])
+def test_ljpeg_round_trip_every_predictor(rng, predictor):
+    from tests.ljpeg_encoder import encode
+    a = rng.integers(0, 1 << 14, (9, 22), dtype=np.uint16)
+    a[3, 5], a[3, 6], a[4, 0] = 0, 16383, 16383                   # large differences of both signs
+    for comps in (1, 2):
+        got = ingest.ljpeg_decode(encode(a, components=comps, precision=14, predictor=predictor))
+        assert got.shape == (9, 22) and np.array_equal(got, a), (predictor, comps)
+
+
+def test_ljpeg_precision_restart_point_transform_and_edges(rng):
+    from tests.ljpeg_encoder import encode
+    full = rng.integers(0, 65536, (8, 12), dtype=np.uint16)      # 16-bit: differences wrap modulo 2^16, category 16 occurs
+    full[0, 0], full[0, 1], full[1, 0], full[1, 1] = 0, 32768, 65535, 0
+    assert np.array_equal(ingest.ljpeg_decode(encode(full, precision=16, predictor=1)), full)
+    assert np.array_equal(ingest.ljpeg_decode(encode(full, components=4, precision=16, predictor=7)), full)
+    twelve = rng.integers(0, 4096, (10, 16), dtype=np.uint16)
+    assert np.array_equal(ingest.ljpeg_decode(encode(twelve, components=2, precision=12, predictor=6, restart_rows=3)), twelve)
+    assert np.array_equal(ingest.ljpeg_decode(encode(twelve, precision=12, predictor=4, restart_rows=1)), twelve)
+    pt = (twelve >> 2) << 2                                       # point transform 2: the low bits are not coded
+    assert np.array_equal(ingest.ljpeg_decode(encode(pt, precision=12, predictor=1, point_transform=2)), pt)
+    flat = np.full((5, 7), 0xff, np.uint16)                       # all-equal samples; 0xFF bytes in the stream get stuffed
+    assert np.array_equal(ingest.ljpeg_decode(encode(flat, precision=8)), flat)
+    good = encode(twelve, precision=12)
+    for bad in (good[:40], b"\xff\xd8\xff\xd9", good.replace(b"\xff\xc3", b"\xff\xc1", 1), b"nope", good[:-len(good) // 2]):
+        with pytest.raises(ValueError, match="Failed to decode RAW"):
+            out = ingest.ljpeg_decode(bad)
+            if bad is good[:-len(good) // 2]:
+                assert out is None
+
+
+def _write_ljpeg_dng(path, cfa, tile=None, comps=2, endian="<"):
+    """A CFA DNG whose raw image is lossless-JPEG compressed: tiles (TileWidth x TileLength, edge tiles padded) or one strip."""
+    from tests.ljpeg_encoder import encode
+    h, w = cfa.shape
+    e = endian
+    if tile:
+        tw, th = tile
+        across, down = (w + tw - 1) // tw, (h + th - 1) // th
+        padded = np.zeros((down * th, across * tw), np.uint16)
+        padded[:h, :w] = cfa
+        padded[h:, :] = padded[h - 1:h, :]                        # what encoders do with the padding: replicate
+        padded[:, w:] = padded[:, w - 1:w]
+        streams = [encode(padded[j * th:(j + 1) * th, i * tw:(i + 1) * tw], components=comps, precision=14, predictor=1)
+                   for j in range(down) for i in range(across)]
+    else:
+        streams = [encode(cfa, components=comps, precision=14, predictor=1)]
+
+    def entry(tag, typ, vals, blob_off):
+        fmt = {3: "H", 4: "I"}[typ]
+        raw = struct.pack(e + fmt * len(vals), *vals)
+        if len(raw) <= 4:
+            return struct.pack(e + "HHI", tag, typ, len(vals)) + raw.ljust(4, b"\0"), b""
+        return struct.pack(e + "HHII", tag, typ, len(vals), blob_off), raw
+
+    def build(entries, base):
+        body, blobs, off = b"", b"", base + 2 + 12 * len(entries) + 4
+        for tag, typ, vals in sorted(entries):
+            ent, blob = entry(tag, typ, vals, off + len(blobs))
+            body += ent
+            blobs += blob
+        return struct.pack(e + "H", len(entries)) + body + struct.pack(e + "I", 0) + blobs
+
+    ents = [(256, 4, [w]), (257, 4, [h]), (258, 3, [14]), (259, 3, [7]), (262, 3, [32803]), (277, 3, [1])]
+    if tile:
+        ents += [(322, 4, [tile[0]]), (323, 4, [tile[1]]), (324, 4, [0] * len(streams)), (325, 4, [len(s) for s in streams])]
+    else:
+        ents += [(278, 4, [h]), (273, 4, [0]), (279, 4, [len(streams[0])])]
+    data_off = 8 + len(build(ents, 8))
+    offs, o = [], data_off
+    for s_ in streams:
+        offs.append(o)
+        o += len(s_)
+    ents = [(t, ty, (offs if t in (324, 273) else v)) for t, ty, v in ents]
+    header = (b"II" if e == "<" else b"MM") + struct.pack(e + "HI", 42, 8)
+    with open(path, "wb") as fh:
+        fh.write(header + build(ents, 8) + b"".join(streams))
+
+
+@pytest.mark.parametrize("layout", ["tiles", "strip"])
+def test_ljpeg_compressed_dng(tmp_path, rng, layout):
+    cfa = rng.integers(0, 1 << 14, (21, 38), dtype=np.uint16)    # 38 x 21 is no multiple of the 16 x 8 tile: edge tiles crop
+    path = tmp_path / f"{layout}.dng"
+    _write_ljpeg_dng(path, cfa, tile=(16, 8) if layout == "tiles" else None, endian=">" if layout == "strip" else "<")
+    r = ingest.load_dng(str(path))
+    assert (r.width, r.height) == (38, 21) and np.array_equal(r.data.reshape(21, 38), cfa)
+    assert r.wb_multipliers == [1.0, 1.0, 1.0, 1.0] and r.color_matrix == list(ra.IDENTITY_MATRIX)   # no metadata tags: neutral
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.load_dng_uncompressed(str(path))                   # the strict entry point still refuses compressed data
+    buf = bytearray(path.read_bytes())
+    k = buf.find(b"\xff\xda") + 40                                # inside the first stream's entropy-coded data
+    buf[k:k + 24] = b"\x55" * 24
+    (tmp_path / "bad.dng").write_bytes(bytes(buf))
+    try:
+        bad = ingest.load_dng(str(tmp_path / "bad.dng"))
+        assert not np.array_equal(bad.data.reshape(21, 38), cfa)  # either an error or different samples, never a crash
+    except ValueError as exc:
+        assert "Failed to decode RAW" in str(exc)
+
+
+def test_ljpeg_decoder_survives_damaged_streams(rng):
+    """The decoder is native code fed from files: 600 random mutations (byte flips, truncations, marker injections) of valid
+    streams must each end in the "Failed to decode RAW" error or in an array of the right shape -- never in a crash."""
+    from tests.ljpeg_encoder import encode
+    a = rng.integers(0, 4096, (12, 20), dtype=np.uint16)
+    streams = [encode(a, components=c, precision=12, predictor=p, restart_rows=r) for c, p, r in ((1, 1, 0), (2, 4, 0), (2, 7, 4))]
+    outcomes = {"error": 0, "array": 0}
+    for it in range(600):
+        b = bytearray(streams[it % 3])
+        kind = it % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            b = b[:int(rng.integers(3, len(b)))]
+        elif kind == 2:
+            k = int(rng.integers(2, len(b) - 2))
+            b[k:k + 2] = bytes([0xff, int(rng.integers(0xc0, 0xff))])
+        else:
+            k = int(rng.integers(2, len(b)))
+            b[k:k] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        try:
+            out = ingest.ljpeg_decode(bytes(b))
+            assert out.ndim == 2 and out.dtype == np.uint16
+            outcomes["array"] += 1
+        except ValueError as exc:
+            assert "Failed to decode RAW" in str(exc) or "reshape" in str(exc), exc
+            outcomes["error"] += 1
+    assert outcomes["error"] > 100, outcomes
+
+
+def test_ljpeg_decoder_under_sanitizers(tmp_path, rng):
+    """The same kind of corpus through the decoder compiled with AddressSanitizer + UBSan (CPU build): 2000 damaged streams,
+    a destination deliberately too small for some frames.  A single out-of-bounds access would abort the child."""
+    import os
+    import subprocess
+    from tests.ljpeg_encoder import encode
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fuzz_ljpeg"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I" + os.path.join(root, "raweditor_amd", "csrc"), os.path.join(root, "tests", "cpp", "fuzz_ljpeg.cpp"),
+                    "-o", str(exe)], check=True)
+    a = rng.integers(0, 65536, (24, 40), dtype=np.uint16)
+    seeds = [encode(a[:12, :20], precision=16), encode(a, components=2, precision=16, predictor=5),
+             encode(a, components=4, precision=16, predictor=7, restart_rows=6), encode(a[:8, :8] >> 4, precision=12, point_transform=1)]
+    with open(tmp_path / "corpus.bin", "wb") as fh:
+        for it in range(2000):
+            b = bytearray(seeds[it % len(seeds)])
+            for _ in range(int(rng.integers(0, 8))):
+                op = int(rng.integers(0, 4))
+                if op == 0 and len(b) > 4:
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+                elif op == 1 and len(b) > 8:
+                    del b[int(rng.integers(4, len(b))):]
+                elif op == 2 and len(b) > 6:
+                    k = int(rng.integers(2, len(b) - 2))
+                    b[k:k + 2] = bytes([0xff, int(rng.integers(0xc0, 0x100))])
+                elif len(b) > 4:
+                    k = int(rng.integers(2, len(b)))
+                    b[k:k] = bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+            fh.write(struct.pack("<I", len(b)) + bytes(b))
+    out = subprocess.run([str(exe), str(tmp_path / "corpus.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    assert "decoded" in out.stdout
