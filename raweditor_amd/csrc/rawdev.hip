@@ -695,7 +695,8 @@ struct rd_batch {
     struct desc_buf {
         rd_frame_desc *dev = nullptr, *host = nullptr;
         size_t cap = 0, n = 0;
-        hipEvent_t done = nullptr;
+        hipEvent_t done = nullptr;             // after the last launch that reads the array
+        hipEvent_t uploaded = nullptr;         // after the copy that filled it (a later call may come on another stream)
         bool valid = false;
     } db[2];
     int db_last = 1;
@@ -736,8 +737,10 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
         b->max_frames = rd_env_u32("RD_BATCH_MAX_FRAMES", fmt == RD_FMT_RGBA_F32 ? 8u : 32u);
     }
     hipError_t e = hipSuccess;
-    for (int j = 0; j < 2 && e == hipSuccess && b->persistent; ++j)
+    for (int j = 0; j < 2 && e == hipSuccess && b->persistent; ++j) {
         e = hipEventCreateWithFlags(&b->db[j].done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->db[j].uploaded, hipEventDisableTiming);
+    }
     if (b->n_streams > 1) {
         e = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
@@ -769,6 +772,7 @@ extern "C" void rd_batch_destroy(rd_batch *b)
             if (d.dev) (void)hipFree(d.dev);
             if (d.host) (void)hipHostFree(d.host);
             if (d.done) (void)hipEventDestroy(d.done);
+            if (d.uploaded) (void)hipEventDestroy(d.uploaded);
         }
         if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
         if (b->ev_join) (void)hipEventDestroy(b->ev_join);
@@ -885,8 +889,11 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
         }
         memcpy(d.host, tmp.data(), n * sizeof(rd_frame_desc));
         RD_HIP(hipMemcpyAsync(d.dev, d.host, n * sizeof(rd_frame_desc), hipMemcpyHostToDevice, s));
+        RD_HIP(hipEventRecord(d.uploaded, s));
         d.n = n;
         d.valid = true;
+    } else {
+        RD_HIP(hipStreamWaitEvent(s, b->db[j].uploaded, 0));     // reused array: its copy may have been enqueued on another stream
     }
     b->db_last = j;
     const rd_frame_desc *descs = b->db[j].dev;

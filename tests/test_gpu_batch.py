@@ -211,3 +211,43 @@ def test_multi_frame_launch_with_heterogeneous_frames(gpu_lib, refc):
                 assert np.array_equal(got.view(np.uint32), exp[i].view(np.uint32)), (misalign, rep, i)
             assert np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist), (misalign, rep)
         be.close()
+
+
+def test_same_batch_on_two_streams_in_turn(gpu_lib, refc):
+    """The descriptor array of a call is kept and reused when the next call brings the same frames -- also when that call
+    comes on another stream: the reuse waits for the copy that filled the array."""
+    import ctypes as C
+    from raweditor_amd import _lib
+    from raweditor_amd._lib import check
+    ra = gpu_lib
+    h, w, n = 260, 384, 6
+    rng = np.random.default_rng([0x52415745, 2020])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    d_out = [DevBuf(h * w * 16) for _ in range(n)]
+    d_hist = DevBuf(768 * 8)
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, True)
+    frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
+    exp_hist = np.zeros(768, np.uint64)
+    exps = []
+    for c, p in zip(cfas, params):
+        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+        exps.append(refc.render_f32(c, u))
+        exp_hist += refc.histogram(refc.pack_u8(exps[-1])).reshape(-1).astype(np.uint64)
+    streams = []
+    for _ in range(2):
+        s = C.c_void_p()
+        check(_lib.lib().rd_stream_create(0, C.byref(s)))
+        streams.append(s.value)
+    for rep in range(4):
+        s = streams[rep % 2]
+        be.develop(frames, stream=s)
+        be.histogram(d_hist.ptr, stream=s)
+        check(_lib.lib().rd_stream_synchronize(0, C.c_void_p(s)))
+        assert np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist), rep
+        for e, o in zip(exps, d_out):
+            assert np.array_equal(o.to_array(np.float32, (h, w, 4)).view(np.uint32), e.view(np.uint32)), rep
+    for s in streams:
+        check(_lib.lib().rd_stream_destroy(0, C.c_void_p(s)))
+    be.close()
