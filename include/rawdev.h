@@ -28,6 +28,9 @@
 extern "C" {
 #endif
 
+/* ABI history.  1: round 1.  2: rd_frame gained `matrix_layout` (the struct grew by one u32); rd_batch_develop packs several
+ * frames into one launch; new entry points rd_node_batch_*, rd_batch_plan_launches, rd_batch_last_launch_count,
+ * rd_pipeline_set_matrix_layout, rd_selftest_q8 / _f16 (+ _codes / _halves), rd_ljpeg_decode, rd_stream_*, rd_debug_*. */
 #define RD_ABI_VERSION 2
 
 typedef enum rd_status {
