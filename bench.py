@@ -317,6 +317,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",                                    # the arithmetic type of the path for EVERY surface format
+        "surface_dtype": {"f32": "f32", "f16": "f16", "u8": "u8"}[args.format],   # what is stored (`--format`)
         "data": "synthetic" if args.data == "uniform" else "synthetic (gradient + 1 % noise)",
         "verified": verified,
         "verified_note": verified_note,
