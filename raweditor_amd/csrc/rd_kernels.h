@@ -50,11 +50,16 @@ __device__ __forceinline__ float rd_dot709(float r, float g, float b)
 }
 
 // a / u.den, correctly rounded (shaders.rs:239).  The denominator is uniform, so its correctly rounded reciprocal u.rden
-// comes from the host; two residual corrections (Markstein: y = RN(1/d), q faithful  =>  RN(q + (a - d*q)*y) = RN(a/d))
-// give the IEEE quotient in 5 FMAs instead of the ~14-instruction generic v_div_scale/v_rcp/v_div_fmas expansion;
-// v_div_fixup_f32 restores the IEEE special cases (a = 0/inf/NaN, d = 0).  u.fast_div is cleared by the host when d or
-// 1/d is not a normal finite number; the generic divide runs then.  tools/div_check.c: 10^9 samples equal.  (The
-// sequence lives in rd_colour_n below, evaluated for all values of a tile behind one branch.)
+// comes from the host, and the quotient is y = RN(1/d), q0 = RN(a*y), then residual corrections q' = RN(q + RN(a - d*q)*y)
+// instead of the ~14-instruction generic v_div_scale/v_rcp/v_div_fmas expansion.
+//   * RD_EL_FIX set (rd_uniforms.h proves a is zero or far from both exponent limits and d is within 2^+-40): ONE correction,
+//     3 FMAs.  Whether q1 == RN(a/d) depends on the two significands only (powers of two scale every intermediate exactly
+//     while nothing leaves the normal range), and tools/div_exhaustive.hip checks ALL 2^23 x 2^23 significand pairs on the
+//     GPU: 0 mismatches in 7.04e13 divisions (profiles/r02_div_exhaustive.txt).
+//   * otherwise, u.fast_div (d and 1/d normal finite numbers): two corrections (Markstein) and v_div_fixup_f32 for the IEEE
+//     special cases (a = 0/inf/NaN); tools/div_check.c: 10^9 samples equal.
+//   * otherwise the generic divide.
+// (The sequence lives in rd_colour_n below, evaluated for all values of a tile behind one branch.)
 
 __device__ __forceinline__ float rd_dot709_c(float r, float g, float b)      // the same dot product, contracted
 {
@@ -140,7 +145,15 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
     if (C) {
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = r[i] * u.rden; g[i] = g[i] * u.rden; b[i] = b[i] * u.rden; }
-    } else if (u.fast_div) {                                     // the reciprocal-correction divide (above) for all 3N values
+    } else if (el & RD_EL_FIX) {                                 // one residual correction (proof: above)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float tr = r[i] * u.rden, tg = g[i] * u.rden, tb = b[i] * u.rden;
+            r[i] = __builtin_fmaf(__builtin_fmaf(-u.den, tr, r[i]), u.rden, tr);
+            g[i] = __builtin_fmaf(__builtin_fmaf(-u.den, tg, g[i]), u.rden, tg);
+            b[i] = __builtin_fmaf(__builtin_fmaf(-u.den, tb, b[i]), u.rden, tb);
+        }
+    } else if (u.fast_div) {                                     // two corrections + the IEEE special cases
         float q[3 * N];
 #pragma unroll
         for (int i = 0; i < N; ++i) { q[3 * i] = r[i]; q[3 * i + 1] = g[i]; q[3 * i + 2] = b[i]; }
@@ -153,16 +166,12 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
             e = __builtin_fmaf(-u.den, t, a);
             q[k] = __builtin_fmaf(e, u.rden, t);
         }
-        if (!(el & RD_EL_FIX)) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                q[3 * i] = __builtin_amdgcn_div_fixupf(q[3 * i], u.den, r[i]);
-                q[3 * i + 1] = __builtin_amdgcn_div_fixupf(q[3 * i + 1], u.den, g[i]);
-                q[3 * i + 2] = __builtin_amdgcn_div_fixupf(q[3 * i + 2], u.den, b[i]);
-            }
+        for (int i = 0; i < N; ++i) {
+            r[i] = __builtin_amdgcn_div_fixupf(q[3 * i], u.den, r[i]);
+            g[i] = __builtin_amdgcn_div_fixupf(q[3 * i + 1], u.den, g[i]);
+            b[i] = __builtin_amdgcn_div_fixupf(q[3 * i + 2], u.den, b[i]);
         }
-#pragma unroll
-        for (int i = 0; i < N; ++i) { r[i] = q[3 * i]; g[i] = q[3 * i + 1]; b[i] = q[3 * i + 2]; }
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = r[i] / u.den; g[i] = g[i] / u.den; b[i] = b[i] / u.den; }

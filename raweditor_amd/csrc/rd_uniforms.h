@@ -41,8 +41,10 @@ enum {
     RD_EL_SH = 16u,      // shadows = 0                                              (:230)
     RD_EL_SAT = 32u,     // saturation = 0: mix(Y, c, 1)                             (:245-247)
     RD_EL_VIB = 64u,     // vibrance = 0: mix(Y2, c, 1)                              (:251-257)
-    RD_EL_FIX = 128u,    // levels divide: numerator finite and far from the exponent limits, so v_div_fixup_f32 only
-                         // ever passes the quotient through (its other cases: NaN, inf, zero denominators, exponent overflow)
+    RD_EL_FIX = 128u,    // levels divide: the numerator is zero or finite and far from BOTH exponent limits and the
+                         // denominator is within 2^+-40, so no intermediate of the one-correction quotient of rd_colour_n
+                         // leaves the normal range (the exhaustive significand proof applies) and none of the IEEE special
+                         // cases (NaN, inf, zero denominators, exponent overflow) can occur
     RD_EL_BLK = 256u,    // blacks = 0: c - 0 = c                                    (:239)
 };
 
@@ -109,8 +111,14 @@ static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const
         if (front && u.shadows == 0.0f) u.elide |= RD_EL_SH;
         if (front && a5 < lim && a6 < lim && a7 < lim && u.fast_div && u.s == 1.0f && u.oms == 0.0f) u.elide |= RD_EL_SAT;
         if (front && a5 < lim && a6 < lim && a7 < lim && a8 < lim && u.fast_div && u.vibrance == 0.0f) u.elide |= RD_EL_VIB;
-        const double ad = __builtin_fabs((double)u.den);
-        if (front && a5 < lim && a6 < lim && a7 < lim && u.fast_div && ad > 1.0e-30 && ad < lim) u.elide |= RD_EL_FIX;
+        // Lower limit of the numerator a = v - blacks, v = (c - 0.5) * cf + 0.5 (shaders.rs:233-239, never skipped in strict
+        // mode): t + 0.5 is exact and a multiple of 2^-25 for t in [-1, -0.25] and at least 0.25 in magnitude otherwise,
+        // so v is 0 or |v| >= 2^-25, a multiple of 2^-48.  With blacks = 0 or |blacks| >= 2^-50 (a multiple of 2^-73) a is
+        // 0 or |a| >= 2^-73; with |den| <= 2^40 the quotient stays above 2^-114 and a non-zero residual a - den*q, a multiple
+        // of 2^(E_a - 47), above 2^-120: all normal.
+        const double ad = __builtin_fabs((double)u.den), abk = __builtin_fabs((double)u.blacks);
+        const bool num_ok = u.blacks == 0.0f || (abk >= 0x1p-50 && abk < lim);
+        if (front && a5 < lim && a6 < lim && a7 < lim && u.fast_div && ad >= 0x1p-40 && ad <= 0x1p40 && num_ok) u.elide |= RD_EL_FIX;
         if (u.blacks == 0.0f) u.elide |= RD_EL_BLK;
     }
     return u;

@@ -232,6 +232,16 @@ def test_identity_step_elision_is_exact(gpu_lib, refc):
                ({}, (1e38, 1e38, 1e38, 1.0), CM_IDENTITY), ({"whites": 0.0, "blacks": 0.0001}, WB_DAYLIGHT, CM_IDENTITY),
                ({"whites": 0.2, "blacks": 0.2, "exposure": 90.0}, WB_DAYLIGHT, CM_IDENTITY),
                ({"exposure": 100.0}, WB_DAYLIGHT, (1e30, 0, 0, 0, 1e30, 0, 0, 0, 1e30))]
+    # the levels divide: sliders for which the one-correction quotient is not proven (RD_EL_FIX clear: the two-correction
+    # sequence with v_div_fixup runs), at its limits (|blacks| around 2^-50, den around 2^40), and numerators that cancel
+    # to zero or to a few ulps (contrast -100 maps every pixel to 0.5; blacks = 0.5 then gives 0 / den)
+    stacks += [({"blacks": 1e-20}, WB_DAYLIGHT, CM_IDENTITY), ({"blacks": -1e-30, "whites": 3e12}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"blacks": 1e-15}, WB_DAYLIGHT, CM_IDENTITY), ({"blacks": 8.8e-16}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"whites": 1.0e12}, WB_DAYLIGHT, CM_IDENTITY), ({"whites": 1.2e12}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"contrast": -100.0, "blacks": 0.5}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"contrast": -100.0, "blacks": 0.49999997}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"contrast": -99.99999, "blacks": 0.5, "whites": 0.5001}, WB_DAYLIGHT, CM_IDENTITY),
+               ({"blacks": 0.3, "whites": 0.2999}, WB_DAYLIGHT, CM_TEST), ({"blacks": -3.0, "whites": 37.0}, WB_DAYLIGHT, CM_TEST)]
     for math in (0, 1):
         for params, wb, cm in stacks:
             exp = oracle(refc, cfa, params, wb, cm, math=math)

@@ -219,6 +219,15 @@ def test_elided_steps_flags():
         assert not tiny & (FIX | SAT | VIB) and tiny & MAT
         nan = ra.elided_steps(ra.EditParams(highlights=float("nan")), wb, ident, math)
         assert not nan & HL
+        # the one-correction quotient (RD_EL_FIX) needs every intermediate in the normal range: a blacks value so small
+        # that the numerator could be subnormal-ish, or a denominator outside 2^+-40, takes the two-correction path
+        assert not ra.elided_steps(ra.EditParams(blacks=1e-20), wb, ident, math) & FIX
+        assert not ra.elided_steps(ra.EditParams(blacks=-1e-30), wb, ident, math) & FIX
+        assert ra.elided_steps(ra.EditParams(blacks=-1e-15), wb, ident, math) & FIX          # |blacks| = 2^-49.8
+        assert ra.elided_steps(ra.EditParams(blacks=-0.0), wb, ident, math) & FIX
+        assert not ra.elided_steps(ra.EditParams(whites=2e12), wb, ident, math) & FIX          # den > 2^40
+        assert not ra.elided_steps(ra.EditParams(whites=-0.0001), wb, ident, math) & FIX      # den = 0
+        assert ra.elided_steps(ra.EditParams(whites=0.5e12), wb, ident, math) & FIX
 
 
 def test_node_batch_dealing_rule_and_no_device():
