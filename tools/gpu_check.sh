@@ -24,7 +24,7 @@ step 900 "$OUT/pytest_gpu.log" python -m pytest tests -m gpu -x -q
 step 600 "$OUT/bench.log" python bench.py --steps 20 --warmup 3
 grep -E '^\{' "$OUT/bench.log" > "$OUT/bench.json" || true
 ( cd /tmp && step 600 "$OLDPWD/$OUT/rocprof_run.log" rocprofv3 --kernel-trace --stats --output-format csv \
-    -d "$OLDPWD/$OUT/rocprof" -- python3 "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline )
+    -d "$OLDPWD/$OUT/rocprof" -- python3 "$OLDPWD/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-alt-math )
 find "$OUT/rocprof" -name "*kernel_stats*.csv" | head -3
 for f in $(find "$OUT/rocprof" -name "*kernel_stats*.csv" | head -1); do head -12 "$f"; done
 echo "== done"
