@@ -59,7 +59,36 @@ __device__ __forceinline__ float rd_dot709(float r, float g, float b)
 //   * otherwise, u.fast_div (d and 1/d normal finite numbers): two corrections (Markstein) and v_div_fixup_f32 for the IEEE
 //     special cases (a = 0/inf/NaN); tools/div_check.c: 10^9 samples equal.
 //   * otherwise the generic divide.
-// (The sequence lives in rd_colour_n below, evaluated for all values of a tile behind one branch.)
+// (rd_levels_divide below: all values of a tile behind one branch.)
+
+// v / u.den for M values (shaders.rs:239), the variants described above; MATH = RD_MATH_CONTRACTED: v * RN(1/den).
+template <int M, int MATH>
+__device__ __forceinline__ void rd_levels_divide(const rd_ku &u, float (&v)[M])
+{
+    if (MATH == RD_MATH_CONTRACTED) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) v[k] = v[k] * u.rden;
+    } else if (u.elide & RD_EL_FIX) {                            // one residual correction (proof: above)
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            const float t = v[k] * u.rden;
+            v[k] = __builtin_fmaf(__builtin_fmaf(-u.den, t, v[k]), u.rden, t);
+        }
+    } else if (u.fast_div) {                                     // two corrections + the IEEE special cases
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            const float a = v[k];
+            float t = a * u.rden;
+            float e = __builtin_fmaf(-u.den, t, a);
+            t = __builtin_fmaf(e, u.rden, t);
+            e = __builtin_fmaf(-u.den, t, a);
+            v[k] = __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, u.rden, t), u.den, a);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < M; ++k) v[k] = v[k] / u.den;
+    }
+}
 
 __device__ __forceinline__ float rd_dot709_c(float r, float g, float b)      // the same dot product, contracted
 {
@@ -142,39 +171,13 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = r[i] - u.blacks; g[i] = g[i] - u.blacks; b[i] = b[i] - u.blacks; }   // :239
     }
-    if (C) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) { r[i] = r[i] * u.rden; g[i] = g[i] * u.rden; b[i] = b[i] * u.rden; }
-    } else if (el & RD_EL_FIX) {                                 // one residual correction (proof: above)
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const float tr = r[i] * u.rden, tg = g[i] * u.rden, tb = b[i] * u.rden;
-            r[i] = __builtin_fmaf(__builtin_fmaf(-u.den, tr, r[i]), u.rden, tr);
-            g[i] = __builtin_fmaf(__builtin_fmaf(-u.den, tg, g[i]), u.rden, tg);
-            b[i] = __builtin_fmaf(__builtin_fmaf(-u.den, tb, b[i]), u.rden, tb);
-        }
-    } else if (u.fast_div) {                                     // two corrections + the IEEE special cases
+    {
         float q[3 * N];
 #pragma unroll
         for (int i = 0; i < N; ++i) { q[3 * i] = r[i]; q[3 * i + 1] = g[i]; q[3 * i + 2] = b[i]; }
+        rd_levels_divide<3 * N, MATH>(u, q);
 #pragma unroll
-        for (int k = 0; k < 3 * N; ++k) {
-            const float a = q[k];
-            float t = a * u.rden;
-            float e = __builtin_fmaf(-u.den, t, a);
-            t = __builtin_fmaf(e, u.rden, t);
-            e = __builtin_fmaf(-u.den, t, a);
-            q[k] = __builtin_fmaf(e, u.rden, t);
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            r[i] = __builtin_amdgcn_div_fixupf(q[3 * i], u.den, r[i]);
-            g[i] = __builtin_amdgcn_div_fixupf(q[3 * i + 1], u.den, g[i]);
-            b[i] = __builtin_amdgcn_div_fixupf(q[3 * i + 2], u.den, b[i]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) { r[i] = r[i] / u.den; g[i] = g[i] / u.den; b[i] = b[i] / u.den; }
+        for (int i = 0; i < N; ++i) { r[i] = q[3 * i]; g[i] = q[3 * i + 1]; b[i] = q[3 * i + 2]; }
     }
     if (!(el & RD_EL_SAT)) {
 #pragma unroll
@@ -207,6 +210,33 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = rd_gamma_clamp(r[i]); g[i] = rd_gamma_clamp(g[i]); b[i] = rd_gamma_clamp(b[i]); }   // :261-264
     }
+}
+
+// The stack for a frame whose channel-mixing steps are all exact identities (RD_EL_SEPARABLE: identity matrix,
+// highlights = shadows = vibrance = 0, saturation = 0): what is left of rd_colour_n acts on each channel alone -- white
+// balance, temperature / tint, exposure, contrast, levels; the same operations in the same order, so the same bits -- and a
+// 2x2 block's three triples (C,A,B), (C,D,A), (C,D,B) hold only five distinct values: v = { r of C; g of A, D; b of B, A }.
+template <int MATH>
+__device__ __forceinline__ void rd_colour_separable(const rd_ku &u, float (&v)[5])
+{
+    constexpr bool C = MATH == RD_MATH_CONTRACTED;
+    const uint32_t el = u.elide;
+    v[0] = v[0] * u.wb_r; v[1] = v[1] * u.wb_g; v[2] = v[2] * u.wb_g; v[3] = v[3] * u.wb_b; v[4] = v[4] * u.wb_b;       // :195
+    if (!(el & RD_EL_K)) {                                                                                         // :200-205
+        v[0] = v[0] * u.kr; v[3] = v[3] * u.kb; v[4] = v[4] * u.kb; v[1] = v[1] * u.kg; v[2] = v[2] * u.kg;
+    }
+    if (!(el & RD_EL_EM)) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = v[k] * u.em;                                                            // :217-218
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)                                                                                    // :233-234
+        v[k] = C ? __builtin_fmaf(v[k] - 0.5f, u.cf, 0.5f) : (v[k] - 0.5f) * u.cf + 0.5f;
+    if (!(el & RD_EL_BLK)) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = v[k] - u.blacks;                                                        // :239
+    }
+    rd_levels_divide<5, MATH>(u, v);
 }
 
 template <int MATH>
@@ -583,17 +613,60 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 #else
         constexpr bool F32T = FMT == RD_FMT_RGBA_F32;      // f32 surface: gamma, histogram and stage write triple by triple (below)
 #endif
+        uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
+        uint32_t ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0, hc0 = 0, hc1 = 0;       // binary16 pairs (r, g), (b, 1.0) of c1, c2, c3 (H16)
+        rd_rgb c1 = { 0.0f, 0.0f, 0.0f }, c2 = c1, c3 = c1;
+        bool separable = false;                                  // wave-uniform
+#ifndef RD_COLOUR_HOOK_HEADER
+        if constexpr (Q8ONLY || H16 || F32T) separable = (u.elide & RD_EL_SEPARABLE) == RD_EL_SEPARABLE;
+        if (separable) {
+            // No step of THIS frame's stack mixes channels (the usual edit): five distinct values instead of nine
+            // (rd_colour_separable); triple 1 = (v0, v1, v3), triple 2 = (v0, v2, v4), triple 3 = (v0, v2, v3).
+            float v[5] = { C, A, D, B, A };
+            rd_colour_separable<MATH>(u, v);
+            if constexpr (Q8ONLY) {
+                q1r = rd_q8_gamma(v[0]); q1g = rd_q8_gamma(v[1]); q1b = rd_q8_gamma(v[3]);
+                q2g = rd_q8_gamma(v[2]); q2b = rd_q8_gamma(v[4]);
+                q2r = q1r; q3r = q1r; q3g = q2g; q3b = q1b;
+                if (HIST && valid) {
+                    if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
+                    if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
+                }
+            } else if constexpr (H16) {
+                uint32_t hr, hg, hb, hg2, hb2;
+                rd_f16_gamma<HIST>(v[0], hr, q1r); rd_f16_gamma<HIST>(v[1], hg, q1g); rd_f16_gamma<HIST>(v[3], hb, q1b);
+                ha0 = hr | (hg << 16); ha1 = hb | 0x3c000000u;
+                if (HIST && valid && has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
+                rd_f16_gamma<HIST>(v[2], hg2, q2g); rd_f16_gamma<HIST>(v[4], hb2, q2b);
+                q2r = q1r; q3r = q1r; q3g = q2g; q3b = q1b;
+                hb0 = hr | (hg2 << 16); hb1 = hb2 | 0x3c000000u;
+                hc0 = hb0; hc1 = ha1;
+                if (HIST && valid && has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
+            } else {                                             // F32T: see the general path below for the stage
+                rd_f4 *st = stage + (size_t)wave * 192u;
+                const rd_rgb g1 = { rd_gamma_clamp(v[0]), rd_gamma_clamp(v[1]), rd_gamma_clamp(v[3]) };
+                if (HIST) { q1r = rd_q8(g1.r); q1g = rd_q8(g1.g); q1b = rd_q8(g1.b); }
+                if (HIST && valid && has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = g1;
+                const rd_rgb g2 = { g1.r, rd_gamma_clamp(v[2]), rd_gamma_clamp(v[4]) };
+                if (HIST) { q2g = rd_q8(g2.g); q2b = rd_q8(g2.b); }
+                if (HIST && valid && has_b) { rd_hist_add(lh, copy, q1r, q2g, q2b, 1u); rd_hist_add(lh, copy, q1r, q2g, q1b, 1u); }
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 1u]) = g2;
+                const rd_rgb g3 = { g1.r, g2.g, g1.b };
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = g3;
+            }
+        }
+#endif
+        if (!separable) {
 #ifdef RD_COLOUR_HOOK_HEADER
-        const rd_rgb c1 = RD_COLOUR(u, C, A, B);
-        const rd_rgb c2 = RD_COLOUR(u, C, D, A);
-        const rd_rgb c3 = RD_COLOUR(u, C, D, B);
+        c1 = RD_COLOUR(u, C, A, B);
+        c2 = RD_COLOUR(u, C, D, A);
+        c3 = RD_COLOUR(u, C, D, B);
 #else
         float tr[3] = { C, C, C }, tg[3] = { A, D, D }, tb[3] = { B, A, B };       // row a: (C,A,B); row b: (C,D,A), (C,D,B)
         rd_colour_n<3, MATH, !(Q8ONLY || H16 || F32T)>(u, tr, tg, tb);
-        const rd_rgb c1 = { tr[0], tg[0], tb[0] }, c2 = { tr[1], tg[1], tb[1] }, c3 = { tr[2], tg[2], tb[2] };
+        c1 = rd_rgb{ tr[0], tg[0], tb[0] }; c2 = rd_rgb{ tr[1], tg[1], tb[1] }; c3 = rd_rgb{ tr[2], tg[2], tb[2] };
 #endif
-        uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
-        uint32_t ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0, hc0 = 0, hc1 = 0;       // binary16 pairs (r, g), (b, 1.0) of c1, c2, c3 (H16)
         if constexpr (Q8ONLY) {
             q1r = rd_q8_gamma(c1.r); q1g = rd_q8_gamma(c1.g); q1b = rd_q8_gamma(c1.b);
             q2r = rd_q8_gamma(c2.r); q2g = rd_q8_gamma(c2.g); q2b = rd_q8_gamma(c2.b);
@@ -633,6 +706,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
             if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
         }
+        }   // !separable
         rd_tile_out<FMT> r;
         if constexpr (FMT == RD_FMT_RGBA_F32) {
             if constexpr (!F32T) {                               // microbench stand-ins only: all three at the end

@@ -46,6 +46,8 @@ enum {
                          // leaves the normal range (the exhaustive significand proof applies) and none of the IEEE special
                          // cases (NaN, inf, zero denominators, exponent overflow) can occur
     RD_EL_BLK = 256u,    // blacks = 0: c - 0 = c                                    (:239)
+    // every step that mixes the channels of a pixel is an identity: the stack acts on r, g and b separately
+    RD_EL_SEPARABLE = RD_EL_MAT | RD_EL_HL | RD_EL_SH | RD_EL_SAT | RD_EL_VIB,
 };
 
 static inline rd_ku rd_make_ku(const rd_edit_params &p, const float wb[4], const float cm[9],

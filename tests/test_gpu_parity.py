@@ -254,6 +254,42 @@ def test_identity_step_elision_is_exact(gpu_lib, refc):
             assert np.array_equal(got_map.view(np.uint32), exp.view(np.uint32)), ("map", math, params)
 
 
+def test_channel_separable_stacks(gpu_lib, refc):
+    """Stacks whose channel-mixing steps are all identities (RD_EL_SEPARABLE: identity matrix, highlights = shadows =
+    vibrance = saturation = 0 -- the usual edit) take rd_colour_separable: five values per 2x2 block instead of nine.
+    Every surface format and the fused histogram must stay bit-identical to the oracle, which never skips anything: both
+    arithmetic modes, full and ragged tiles (256 / 130 / 6 columns), 1- and 2-row frames, a black level, zeros and
+    saturated samples in the CFA, levels sliders on both divide paths; and a stack one slider away from separable."""
+    ra = gpu_lib
+    rng = np.random.default_rng(77)
+    sep = [{}, {"exposure": 0.7, "contrast": 5.0, "whites": 1.05, "blacks": 0.02}, {"exposure": -1.3, "temperature": 0.25, "tint": -0.15},
+           {"contrast": -100.0, "blacks": 0.5}, {"blacks": 1e-20, "whites": 0.9}, {"temperature": -1.0, "tint": 1.0, "contrast": 100.0},
+           {"exposure": 5.0, "blacks": -0.2, "whites": 0.4}]
+    for s in sep:
+        assert ra.elided_steps(ra.EditParams(**s), WB_DAYLIGHT, CM_IDENTITY, 0) & 0x7a == 0x7a, s     # MAT | HL | SH | SAT | VIB
+    almost = [{"exposure": 0.7, "vibrance": 1e-6}, {"contrast": 5.0, "saturation": 1e-4}, {"highlights": 1e-7}, {"shadows": -1e-7}]
+    for (h, w) in ((36, 256), (5, 130), (2, 6), (1, 256), (7, 384)):
+        cfa = random_cfa(rng, h, w, 65536)
+        cfa[::3, ::5] = 0
+        cfa[1::4, 2::7] = 65535
+        for math in (0, 1):
+            for params in sep + almost:
+                for bl in (0, 600):
+                    if bl and params is not sep[1]:
+                        continue
+                    pipe = make_pipe(ra, cfa, params, WB_DAYLIGHT, CM_IDENTITY, bl=bl, math=math)
+                    exp = oracle(refc, cfa, params, WB_DAYLIGHT, CM_IDENTITY, bl=bl, math=math)
+                    check_all_surfaces(ra, refc, pipe, exp)
+                    if w % 128 == 0:
+                        rgb, hist = pipe.render(fmt=ra.FMT_RGB_U8, with_histogram=True)
+                        u8 = refc.pack_u8(exp)
+                        assert np.array_equal(rgb, u8[..., :3]) and np.array_equal(hist, refc.histogram(u8)), (params, math)
+    # the camera matrix switches the path off again
+    cfa = random_cfa(rng, 12, 256, 65536)
+    pipe = make_pipe(ra, cfa, sep[1], WB_DAYLIGHT, CM_TEST)
+    check_all_surfaces(ra, refc, pipe, oracle(refc, cfa, sep[1], WB_DAYLIGHT, CM_TEST))
+
+
 def test_black_level_extension(gpu_lib, refc):
     ra = gpu_lib
     cfa = random_cfa(np.random.default_rng(9), 18, 26)
