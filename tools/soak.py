@@ -26,8 +26,13 @@ def main():
         outs = [DevBuf(H * W * bpp) for _ in range(NF)]
         hist = DevBuf(768 * 8)
         be = ra.BatchExporter(0, W, H, fmt, True)
-        ps = [ra.EditParams.random(np.random.default_rng([7, i])) for i in range(NF)]
+        # even frames: all ten sliders + camera matrix (the general path); odd frames: a usual edit with the identity matrix
+        # (the channel-separable path) -- a launch switches paths at every frame boundary
+        ps = [ra.EditParams.random(np.random.default_rng([7, i])) if i % 2 == 0 else
+              ra.EditParams(exposure=0.3 * i, contrast=5.0, whites=1.05, blacks=0.02, temperature=0.1) for i in range(NF)]
         fr = be.make_frames([b.ptr for b in ins], [b.ptr for b in outs], ps, WB, CM)
+        for i in range(1, NF, 2):
+            fr[i].color_matrix[:] = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
         be.develop(fr, row_bands=bands); be.histogram(hist.ptr); sync()
         h1 = hist.to_array(np.uint64, (768,)).copy()
         first = [o.to_array(np.uint8, (H * W * bpp,)).copy() for o in outs[:2]]
