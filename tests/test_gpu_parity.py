@@ -504,3 +504,14 @@ def test_matrix_layout_option(gpu_lib, refc, rng):
     with pytest.raises(ra.RawdevError):
         be.develop(fr)
     be.close()
+
+
+def test_differential_fuzz_sample(gpu_lib):
+    """400 draws of tests/fuzz_parity.py (random sizes, sliders on and off and far outside the UI, matrices, black levels,
+    both arithmetic modes; 8 renders per frame against the oracle).  profiles/r02_fuzz_parity.txt holds a 200 000-frame run."""
+    from tests import fuzz_parity as fz
+    rng = np.random.default_rng([0x52415745, 99])
+    for i in range(400):
+        case = fz.draw_case(rng)
+        bad, _ = fz.check(case)
+        assert not bad, (i, bad, case[0].shape, case[1:])
