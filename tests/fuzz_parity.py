@@ -112,6 +112,67 @@ def check(case):
     return bad, flags
 
 
+def check_batch(rng):
+    """One rd_batch_develop call over 1-12 heterogeneous frames (own stack, white balance, matrix and black level each), a
+    random surface format, row bands, frames-per-launch cap and arithmetic mode, run twice; every surface and the
+    accumulated histogram against the oracle.  Returns (mismatch descriptions, frames)."""
+    from raweditor_amd._lib import RdFrame
+    from tests.gpu_util import DevBuf, sync
+    w = int(2 * rng.integers(1, 200)) if rng.random() < 0.6 else int(128 * rng.integers(1, 9))   # batch: even widths
+    h = int(rng.integers(1, 60))
+    n = int(rng.integers(1, 13))
+    math = int(rng.integers(0, 2))
+    fmt, dtype, ch, pack = [(ra.FMT_RGBA_F32, np.float32, 4, None), (ra.FMT_RGBA_U8, np.uint8, 4, refc.pack_u8),
+                            (ra.FMT_RGBA_F16, np.uint16, 4, refc.pack_f16)][rng.integers(0, 3)]
+    bands = int(rng.integers(1, 4))
+    cap = rng.choice(("", "1", "2", "3", "8"))
+    cases = []
+    for _ in range(n):
+        cfa, params, wb, cm, bl, _m = draw_case(rng)
+        hi = 65536 if rng.random() < 0.3 else 4096
+        cases.append((rng.integers(0, hi, (h, w), dtype=np.uint16), params, wb, cm, bl))
+    exp, exp_hist = [], np.zeros(768, np.uint64)
+    for cfa, params, wb, cm, bl in cases:
+        e = refc.render_f32(cfa, refc.make_uniforms(params, wb, cm, 1.0, 0.0, 0.0, bl, math), None, None, nthreads=8)
+        exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
+        exp.append(e if pack is None else pack(e))
+    if cap:
+        os.environ["RD_BATCH_MAX_FRAMES"] = cap
+    try:
+        be = ra.BatchExporter(0, w, h, fmt, True, math_mode=math)
+    finally:
+        os.environ.pop("RD_BATCH_MAX_FRAMES", None)
+    d_in = [DevBuf.from_array(c[0]) for c in cases]
+    d_out = [DevBuf(h * w * ra.BYTES_PER_PIXEL[fmt]) for _ in range(n)]
+    d_hist = DevBuf(768 * 8)
+    frames = (RdFrame * n)()
+    for i, (cfa, params, wb, cm, bl) in enumerate(cases):
+        frames[i].cfa_dev = d_in[i].ptr
+        frames[i].out_dev = d_out[i].ptr
+        frames[i].params = ra.EditParams(**params).to_c()
+        frames[i].wb_multipliers[:] = [float(x) for x in wb]
+        frames[i].color_matrix[:] = [float(x) for x in cm]
+        frames[i].black_level = bl
+    bad = []
+    for rep in range(2):
+        be.develop(frames, row_bands=bands)
+        be.histogram(d_hist.ptr)
+        sync()
+        for i in range(n):
+            got = d_out[i].to_array(dtype, (h, w, ch))
+            e = exp[i]
+            same = np.array_equal(got.view(np.uint32), e.view(np.uint32)) if dtype is np.float32 else \
+                np.array_equal(got, e.view(dtype).reshape(got.shape))
+            if not same:
+                bad.append(f"frame {i} pass {rep}")
+        if not np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist):
+            bad.append(f"histogram pass {rep}")
+    be.close()
+    if bad:
+        bad.append(f"[{w}x{h}, {n} frames, fmt {fmt}, bands {bands}, cap {cap!r}, math {math}]")
+    return bad, n
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -130,10 +191,20 @@ def main():
                   flush=True)
         if i % 250 == 249:
             print(f"{i + 1} cases, {fails} mismatching", flush=True)
+    nb, bfails, bframes = max(1, n // 20), 0, 0
+    for i in range(nb):
+        bad, k = check_batch(rng)
+        bframes += k
+        if bad:
+            bfails += 1
+            print(f"batch call {i}: MISMATCH {bad}", flush=True)
+    print(f"fuzz_parity seed {seed}: {nb} rd_batch_develop calls ({bframes} heterogeneous frames, random format / row bands / frames per "
+          f"launch / arithmetic mode, two passes each; surfaces and the accumulated histogram against the oracle): {bfails} mismatching calls")
+    fails_total = fails + bfails
     print(f"fuzz_parity seed {seed}: {n} random frames ({px} pixels; {sep} channel-separable stacks, {fix} with the one-correction "
           f"divide, {n - fix} on the other divide paths), 8 renders each (f32 / RGBA8 / f16 + histograms, RGB8, map kernel) against "
           f"the oracle: {fails} mismatching frames, {time.perf_counter() - t0:.0f} s")
-    return 1 if fails else 0
+    return 1 if fails_total else 0
 
 
 if __name__ == "__main__":

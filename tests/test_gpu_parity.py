@@ -515,3 +515,6 @@ def test_differential_fuzz_sample(gpu_lib):
         case = fz.draw_case(rng)
         bad, _ = fz.check(case)
         assert not bad, (i, bad, case[0].shape, case[1:])
+    for i in range(25):                                          # rd_batch_develop: heterogeneous frames, random launch shapes
+        bad, _ = fz.check_batch(rng)
+        assert not bad, (i, bad)
