@@ -68,7 +68,7 @@ def draw_case(rng):
     return cfa, draw_params(rng), wb, cm, bl, int(rng.integers(0, 2))
 
 
-def check(case):
+def check(case, view=None):
     cfa, params, wb, cm, bl, math = case
     h, w = cfa.shape
     ep = ra.EditParams(**params)
@@ -108,6 +108,19 @@ def check(case):
     if not np.array_equal(gm.view(np.uint32), exp.view(np.uint32)):
         bad.append("f32(map)")
     flags = ra.elided_steps(ep, wb, cm, math)
+    if view is not None:                                         # the point-sampling map: target size, zoom, pan (shaders.rs:23-60)
+        tw, th, zoom, px_, py_ = view
+        pipe.update_uniforms_with_zoom(ep, zoom, px_, py_)
+        uz = refc.make_uniforms(params, wb, cm, zoom, px_, py_, bl, math)
+        ez = refc.render_f32(cfa, uz, tw, th, nthreads=8)
+        gz, hz = pipe.render(tw, th, ra.FMT_RGBA_F32, with_histogram=True)
+        if not np.array_equal(gz.view(np.uint32), ez.view(np.uint32)):
+            bad.append(f"f32(view {view})")
+        if not np.array_equal(hz, refc.histogram(refc.pack_u8(ez))):
+            bad.append(f"hist(view {view})")
+        g8 = pipe.render(tw, th, ra.FMT_RGBA_U8)
+        if not np.array_equal(g8, refc.pack_u8(ez)):
+            bad.append(f"u8(view {view})")
     pipe.close()
     return bad, flags
 
@@ -178,10 +191,15 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng([0x52415745, seed])
     t0 = time.perf_counter()
-    fails, px, sep, fix, nofast = 0, 0, 0, 0, 0
+    fails, px, sep, fix, views = 0, 0, 0, 0, 0
     for i in range(n):
         case = draw_case(rng)
-        bad, flags = check(case)
+        view = None
+        if rng.random() < 0.5:
+            view = (int(rng.integers(1, 300)), int(rng.integers(1, 200)), float(F(rng.choice((1.0, rng.uniform(0.3, 8.0))))),
+                    float(F(rng.uniform(-0.7, 0.7))), float(F(rng.uniform(-0.7, 0.7))))
+            views += 1
+        bad, flags = check(case, view)
         px += case[0].size
         sep += (flags & 0x7a) == 0x7a
         fix += bool(flags & 128)
@@ -202,8 +220,8 @@ def main():
           f"launch / arithmetic mode, two passes each; surfaces and the accumulated histogram against the oracle): {bfails} mismatching calls")
     fails_total = fails + bfails
     print(f"fuzz_parity seed {seed}: {n} random frames ({px} pixels; {sep} channel-separable stacks, {fix} with the one-correction "
-          f"divide, {n - fix} on the other divide paths), 8 renders each (f32 / RGBA8 / f16 + histograms, RGB8, map kernel) against "
-          f"the oracle: {fails} mismatching frames, {time.perf_counter() - t0:.0f} s")
+          f"divide, {n - fix} on the other divide paths), 8 renders each (f32 / RGBA8 / f16 + histograms, RGB8, map kernel), {views} of them also as a zoomed / panned "
+          f"view of random size (f32 + histogram, RGBA8), against the oracle: {fails} mismatching frames, {time.perf_counter() - t0:.0f} s")
     return 1 if fails_total else 0
 
 
