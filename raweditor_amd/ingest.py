@@ -35,6 +35,13 @@ class RawDataResult:
     height: int
     wb_multipliers: List[float]      # [R/G, 1, B/G, G2/G]
     color_matrix: List[float]        # xyz_to_cam 3x3 row-major (or identity)
+    # Extras the reference's struct does not carry (loader.rs drops them: its shader divides by 4096 whatever the sensor,
+    # shaders.rs:167-168, and hard-codes RGGB, :127-155).  Filled from the container when it states them; the defaults are
+    # what the reference assumes, and nothing applies them unless the caller passes black_level on (rd_frame.black_level).
+    black_level: int = 0             # one level for the whole plane: the mean of the container's per-channel levels, rounded
+    white_level: int = 65535
+    cfa_pattern: str = "RGGB"        # 2x2 repeat, row-major; the develop path demosaics RGGB only
+    black_levels: List[float] = dataclasses.field(default_factory=list)    # as stated by the container (1, 2x2 ... values)
 
 
 def normalise_wb(wb_coeffs: Sequence[float]) -> List[float]:
@@ -97,6 +104,7 @@ TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 25
 TAG_STRIP_OFFSETS, TAG_SPP, TAG_ROWS_PER_STRIP, TAG_STRIP_BYTES, TAG_SUBIFD = 273, 277, 278, 279, 330
 TAG_TILE_WIDTH, TAG_TILE_LENGTH, TAG_TILE_OFFSETS, TAG_TILE_BYTES = 322, 323, 324, 325
 TAG_COLOR_MATRIX1, TAG_AS_SHOT_NEUTRAL = 50721, 50728
+TAG_CFA_REPEAT_DIM, TAG_CFA_PATTERN, TAG_BLACK_LEVEL, TAG_WHITE_LEVEL = 33421, 33422, 50714, 50717
 COMPRESSION_NONE, COMPRESSION_LJPEG = 1, 7
 PHOTOMETRIC_CFA = 32803
 
@@ -290,4 +298,18 @@ def _finish(ifds, raw, data, w, h) -> RawDataResult:
     wb = [1.0 / x if x else 0.0 for x in neutral[:3]] if neutral else []      # multipliers = 1 / neutral
     cm = meta.get(TAG_COLOR_MATRIX1) or raw.get(TAG_COLOR_MATRIX1)
     xyz_to_cam = [cm[0:3], cm[3:6], cm[6:9]] if cm and len(cm) >= 9 else None
-    return RawDataResult(data, int(w), int(h), normalise_wb(wb), extract_matrix(xyz_to_cam))
+    res = RawDataResult(data, int(w), int(h), normalise_wb(wb), extract_matrix(xyz_to_cam))
+    # DNG 1.x: BlackLevel (one value, or one per position of BlackLevelRepeatDim), WhiteLevel, CFAPattern (0 R, 1 G, 2 B)
+    levels = [float(x) for x in raw.get(TAG_BLACK_LEVEL, []) if isinstance(x, (int, float)) and math.isfinite(float(x))]
+    if levels:
+        res.black_levels = levels
+        res.black_level = int(min(max(round(sum(levels) / len(levels)), 0), 65535))
+    white = [x for x in raw.get(TAG_WHITE_LEVEL, []) if isinstance(x, (int, float))]
+    if white:
+        res.white_level = int(min(max(round(float(white[0])), 0), 65535))
+    pat = raw.get(TAG_CFA_PATTERN, [])
+    if len(pat) == 1 and isinstance(pat[0], (bytes, bytearray)):              # type UNDEFINED arrives as raw bytes
+        pat = list(pat[0])
+    if len(pat) == 4 and raw.get(TAG_CFA_REPEAT_DIM, [2, 2])[:2] == [2, 2] and all(isinstance(c, int) and 0 <= c <= 2 for c in pat):
+        res.cfa_pattern = "".join("RGB"[c] for c in pat)
+    return res

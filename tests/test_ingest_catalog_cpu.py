@@ -80,7 +80,7 @@ def _pack_rows(cfa, bits):
     return np.packbits(b, axis=1)                        # pads each row with zero bits
 
 
-def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2, bits=16):
+def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2, bits=16, extra_raw_tags=()):
     """A minimal uncompressed CFA DNG: IFD0 (thumbnail-less metadata) -> SubIFD with the raw strips."""
     h, w = cfa.shape
     e = endian
@@ -94,8 +94,8 @@ def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2, b
     chunks = [c for c in chunks if c]
 
     def entry(tag, typ, vals, blob_off):
-        fmt = {3: "H", 4: "I", 10: "i"}[typ]
-        n = len(vals) // (2 if typ == 10 else 1)
+        fmt = {1: "B", 3: "H", 4: "I", 5: "I", 10: "i"}[typ]
+        n = len(vals) // (2 if typ in (5, 10) else 1)
         raw = struct.pack(e + fmt * len(vals), *vals)
         if len(raw) <= 4:
             return struct.pack(e + "HHI", tag, typ, n) + raw.ljust(4, b"\0"), b""
@@ -116,7 +116,7 @@ def _write_dng(path, cfa, endian="<", neutral=(0.5, 1.0, 2.0 / 3.0), strips=2, b
     ifd0_len = len(build_ifd(ifd0_entries, 8))
     sub_off = 8 + ifd0_len
     sub_entries = [(256, 4, [w]), (257, 4, [h]), (258, 3, [bits]), (259, 3, [1]), (262, 3, [32803]), (277, 3, [1]),
-                   (278, 4, [rows]), (273, 4, [0] * len(chunks)), (279, 4, [len(c) for c in chunks])]
+                   (278, 4, [rows]), (273, 4, [0] * len(chunks)), (279, 4, [len(c) for c in chunks])] + list(extra_raw_tags)
     sub_len = len(build_ifd(sub_entries, sub_off))
     data_off = sub_off + sub_len
     offs, o = [], data_off
@@ -141,6 +141,25 @@ def test_uncompressed_dng(tmp_path, rng, endian):
     (tmp_path / "junk.dng").write_bytes(b"not a tiff at all")
     with pytest.raises(ValueError, match="Failed to decode RAW"):
         ingest.load_dng_uncompressed(str(tmp_path / "junk.dng"))
+
+
+def test_dng_levels_and_cfa_pattern(tmp_path, rng):
+    """BlackLevel / WhiteLevel / CFAPattern travel with the result as extras (the reference's struct drops them); a file
+    without them keeps the reference's assumptions."""
+    cfa = rng.integers(0, 4096, (6, 8), dtype=np.uint16)
+    p = tmp_path / "levels.dng"
+    _write_dng(p, cfa, extra_raw_tags=[(50713, 3, [2, 2]), (50714, 5, [2560, 10, 2570, 10, 2570, 10, 2580, 10]), (50717, 3, [4095]),
+                                       (33421, 3, [2, 2]), (33422, 1, [1, 0, 2, 1])])
+    r = ingest.load_dng(str(p))
+    assert np.array_equal(r.data.reshape(6, 8), cfa)
+    assert r.black_levels == pytest.approx([256.0, 257.0, 257.0, 258.0]) and r.black_level == 257
+    assert r.white_level == 4095 and r.cfa_pattern == "GRBG"
+    _write_dng(p, cfa, extra_raw_tags=[(50714, 4, [64])])
+    r = ingest.load_dng(str(p))
+    assert (r.black_level, r.black_levels, r.white_level, r.cfa_pattern) == (64, [64.0], 65535, "RGGB")
+    _write_dng(p, cfa)
+    r = ingest.load_dng(str(p))
+    assert (r.black_level, r.black_levels, r.white_level, r.cfa_pattern) == (0, [], 65535, "RGGB")
 
 
 def test_damaged_tiff_containers_fail_cleanly(tmp_path, rng):
