@@ -27,6 +27,7 @@ def main():
     stacks = {
         "all sliders default, identity matrix": (lambda i: ra.EditParams(), IDENT),
         "exposure + contrast + whites/blacks, identity matrix": (lambda i: ra.EditParams(exposure=0.7, contrast=5.0, whites=1.05, blacks=0.02), IDENT),
+        "exposure + contrast + vibrance + saturation, identity": (lambda i: ra.EditParams(exposure=0.5, contrast=8.0, vibrance=0.4, saturation=15.0), IDENT),
         "exposure + highlights + shadows + temperature, identity": (lambda i: ra.EditParams(exposure=-0.4, highlights=-0.5, shadows=0.3, temperature=0.2), IDENT),
         "all ten sliders randomised, identity matrix": (lambda i: ra.EditParams.random(np.random.default_rng([7, i])), IDENT),
         "all ten sliders randomised, camera matrix (bench.py)": (lambda i: ra.EditParams.random(np.random.default_rng([7, i])), CM),
