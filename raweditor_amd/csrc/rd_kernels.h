@@ -618,7 +618,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         rd_rgb c1 = { 0.0f, 0.0f, 0.0f }, c2 = c1, c3 = c1;
         bool separable = false;                                  // wave-uniform
 #ifndef RD_COLOUR_HOOK_HEADER
-        if constexpr (Q8ONLY || H16 || F32T) separable = (u.elide & RD_EL_SEPARABLE) == RD_EL_SEPARABLE;
+        // (not for the f32 surface: it sits on its memory floor with or without the shortcut -- 76.5 us per frame either way --
+        // and the extra path costs its general case 0.3 %)
+        if constexpr (Q8ONLY || H16) separable = (u.elide & RD_EL_SEPARABLE) == RD_EL_SEPARABLE;
         if (separable) {
             // No step of THIS frame's stack mixes channels (the usual edit): five distinct values instead of nine
             // (rd_colour_separable); triple 1 = (v0, v1, v3), triple 2 = (v0, v2, v4), triple 3 = (v0, v2, v3).
@@ -642,18 +644,6 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 hb0 = hr | (hg2 << 16); hb1 = hb2 | 0x3c000000u;
                 hc0 = hb0; hc1 = ha1;
                 if (HIST && valid && has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
-            } else {                                             // F32T: see the general path below for the stage
-                rd_f4 *st = stage + (size_t)wave * 192u;
-                const rd_rgb g1 = { rd_gamma_clamp(v[0]), rd_gamma_clamp(v[1]), rd_gamma_clamp(v[3]) };
-                if (HIST) { q1r = rd_q8(g1.r); q1g = rd_q8(g1.g); q1b = rd_q8(g1.b); }
-                if (HIST && valid && has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
-                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = g1;
-                const rd_rgb g2 = { g1.r, rd_gamma_clamp(v[2]), rd_gamma_clamp(v[4]) };
-                if (HIST) { q2g = rd_q8(g2.g); q2b = rd_q8(g2.b); }
-                if (HIST && valid && has_b) { rd_hist_add(lh, copy, q1r, q2g, q2b, 1u); rd_hist_add(lh, copy, q1r, q2g, q1b, 1u); }
-                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 1u]) = g2;
-                const rd_rgb g3 = { g1.r, g2.g, g1.b };
-                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = g3;
             }
         }
 #endif
