@@ -6,22 +6,32 @@ also config 4's share): a batch of 256 distinct synthetic 24 MP RGGB frames (601
 uniform 12-bit, seed 0x52415745) resident in HBM, one randomised slider stack per frame drawn from
 the UI ranges, wb = (2, 1, 1.5), non-identity colour matrix, RGBA-f32 surface written to a ring of
 output buffers, fused 3x256 histogram accumulated in u64.  One "step" = one pass over the batch:
-the fused launches of rd_batch_develop (up to 8 frames each) + the histogram fold (+ one RCCL all-reduce of 768 x i64 when N > 1).
+the fused launches of rd_batch_develop (up to 8 frames each) + the histogram fold (+ one RCCL
+all-reduce of 768 x i64 when N > 1).  Consecutive steps submit DIFFERENT frame descriptors (the
+slider stacks of the two halves of the batch are swapped every other step), so every step pays the
+descriptor upload a real export pays (--static-descriptors restores the resubmission of one array).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                     # N > 1 without a launcher: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --host node --gpus N ...         # ONE process, rd_node_batch_* (what a Rust / C host calls)
 
 Prints ONE JSON line on rank 0.  `value` counts output pixels of all ranks over the max-over-ranks
 wall time of exactly K steps, inputs already resident in HBM.  `roofline` is the dominant kernel
-(rd_develop_quads) against the 8 TB/s HBM3E peak with the algorithmic 18 B/px of BASELINE.md section 2;
+(rd_develop_batch) against the 8 TB/s HBM3E peak with the algorithmic 18 B/px of BASELINE.md section 2;
 its launch duration is measured here with HIP events on the launch stream.  `cpu_baseline` is the
 oracle (oracle/develop_ref.c, a port -- the reference has no CPU path) on the host cores, rank 0,
-N = 1 only, reported-only.
+N = 1 only, reported-only.  `extra_configs` (N = 1, after the headline and outside its timed region):
+BASELINE config 1 (one 24 MP frame, launch + synchronise latency), the reference's own RGBA8
+surface on the batch workload, and the config-5 shape (100 MP frames, f16 surface), each with its
+own roofline figures and oracle check.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +46,7 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spe
 BYTES_PER_PX = {"f32": 18, "f16": 10, "u8": 6}   # 2 B CFA read + surface write
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -49,17 +59,87 @@ def parse_args():
     ap.add_argument("--row-bands", type=int, default=1)
     ap.add_argument("--math", choices=["strict", "contracted"], default="strict",
                     help="arithmetic of the colour stack (rd_math_mode); strict = literal WGSL order (default)")
+    ap.add_argument("--host", choices=["ranks", "node"], default="ranks",
+                    help="ranks: one process per GPU + torch.distributed (the driver's contract; default).  node: ONE "
+                         "process drives all GPUs through rd_node_batch_* (the C-ABI entry a Rust / C host uses; the "
+                         "histogram all-reduce happens inside librawdev over RCCL)")
+    ap.add_argument("--static-descriptors", action="store_true",
+                    help="resubmit ONE frame array every step (librawdev then skips the descriptor upload); default: the "
+                         "steps alternate between two arrays so every step uploads its descriptors")
     ap.add_argument("--no-alt-math", action="store_true",
                     help="skip the short extra run in the other math mode (reported under 'alt_math', N=1 only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip 'extra_configs' (config 1, RGBA8, config-5 shape; N=1 only)")
     ap.add_argument("--no-hist", action="store_true")
     ap.add_argument("--data", choices=["uniform", "gradient"], default="uniform",
                     help="uniform: i.i.d. 12-bit samples (SURVEY 8d, the headline); gradient: smooth ramp + 1 %% noise "
                          "(SURVEY 8d's second distribution: flat regions, same-bin histogram atomics, less bit toggling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with N > 1 and no launcher environment
+# ------------------------------------------------------------------------------------------------
+def child_env(base_env, rank, world, port):
+    """Environment of rank `rank` of `world` single-node rank processes (what torch.distributed.run would export)."""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GROUP_RANK": "0", "ROLE_RANK": str(rank)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what this pool's host driver supports
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return env
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(world, argv, script=None):
+    """Start `world` fresh rank processes of this script (never a re-exec of this process, which has not touched the GPU
+    or torch.cuda), relay rank 0's stdout, return non-zero if any rank fails.  Ranks > 0 write to stderr."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(cmd, env=child_env(os.environ, r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+
+    def relay():                                              # rank 0 prints the JSON line
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc, deadline, pending = 0, None, list(procs)
+    try:
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or (code if code > 0 else 1)
+                    if deadline is None:
+                        deadline = time.time() + 20.0         # a rank died: the others cannot finish; stop them soon
+            if deadline is not None and time.time() > deadline:
+                for p in pending:
+                    p.kill()                                  # exactly the PIDs started here
+                deadline = float("inf")
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    t.join(timeout=5.0)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
 def usable_cores():
     """Threads worth starting: the CPUs this process may run on, capped by the cgroup's CPU quota (a GPU box gives a
     one-GPU job a share of the host -- 256 hardware threads are visible, far fewer can run at once)."""
@@ -127,52 +207,260 @@ def cpu_baseline(width, height, budget_s):
                       f"arithmetic-bound (one thread: {one_thread:.1f} MP/s), reported-only"}
 
 
-def verify_outputs(ra, fmt_name, W, H, cfas, params, ring, n_frames, row_bands, math_name):
-    """Outside the timed region: download two surfaces of the output ring as the timed passes left them and compare
-    four row bands of each with the oracle, bit for bit (the histogram sum alone would pass for garbage pixels).
-    Slot s of the ring was last written by frame n_frames - len(ring) + s (frames go to slot i % len(ring))."""
+def check_bands(fmt_name, W, H, cfa_t, p, surf_t, math_name, label):
+    """Four row bands of one surface (a torch uint8 tensor on the device, sliced there) against the oracle, bit for bit."""
     import numpy as np
     from oracle import ref_c                       # the checker, never the thing measured
     from raweditor_amd import FIELDS
     math_mode = ref_c.MATH_CONTRACTED if math_name == "contracted" else ref_c.MATH_STRICT
     mid = (H // 2) | 1
     bands = [(0, min(6, H)), (max(0, min(1001, H - 6)), min(1007, H)), (mid, min(mid + 2, H)), (max(0, H - 6), H)]
+    bpp = {"f32": 16, "f16": 8, "u8": 4}[fmt_name]
+    cfa = cfa_t.cpu().numpy().view(np.uint16)
+    u = ref_c.make_uniforms({f: getattr(p, f) for f in FIELDS}, WB, CM, math_mode=math_mode)
+    rows = surf_t.view(H, W * bpp)
+    for r0, r1 in bands:
+        exp = ref_c.render_band(cfa, u, r0, r1)
+        raw = rows[r0:r1].cpu().numpy()
+        if fmt_name == "f32":
+            ok = np.array_equal(raw.view(np.uint32).reshape(r1 - r0, W, 4), exp.view(np.uint32))
+        elif fmt_name == "f16":
+            ok = np.array_equal(raw.view(np.uint16).reshape(r1 - r0, W, 4), ref_c.pack_f16(exp).view(np.uint16))
+        else:
+            ok = np.array_equal(raw.reshape(r1 - r0, W, 4), ref_c.pack_u8(exp))
+        if not ok:
+            return False, f"{label} rows {r0}..{r1} differ from the oracle"
+    return True, len(bands)
+
+
+def verify_outputs(fmt_name, W, H, cfas, params_last, ring, n_frames, math_name):
+    """Outside the timed region: two surfaces of the output ring as the timed passes left them, four row bands each,
+    against the oracle (the histogram sum alone would pass for garbage pixels).  Slot s of the ring was last written by
+    frame n_frames - len(ring) + s (frames go to slot i % len(ring)) with the stacks of the LAST step (`params_last`)."""
     nring = len(ring)
-    checked = []
+    checked, nb = [], 0
     for slot in sorted({0, nring - 1}):
         owners = [i for i in range(n_frames) if i % nring == slot]
         if not owners:
             continue
         i = owners[-1]
-        cfa = cfas[i].cpu().numpy().view(np.uint16)
-        u = ref_c.make_uniforms({f: getattr(params[i], f) for f in FIELDS}, WB, CM, math_mode=math_mode)
-        raw = ring[slot].cpu().numpy()
-        for r0, r1 in bands:
-            exp = ref_c.render_band(cfa, u, r0, r1)
-            if fmt_name == "f32":
-                got = raw.view(np.float32).reshape(H, W, 4)[r0:r1]
-                ok = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
-            elif fmt_name == "f16":
-                got = raw.view(np.uint16).reshape(H, W, 4)[r0:r1]
-                ok = np.array_equal(got, ref_c.pack_f16(exp).view(np.uint16))
-            else:
-                got = raw.reshape(H, W, 4)[r0:r1]
-                ok = np.array_equal(got, ref_c.pack_u8(exp))
-            if not ok:
-                return False, f"frame {i} (ring slot {slot}) rows {r0}..{r1} differ from the oracle"
+        ok, info = check_bands(fmt_name, W, H, cfas[i], params_last[i], ring[slot], math_name, f"frame {i} (ring slot {slot})")
+        if not ok:
+            return False, info
+        nb = info
         checked.append(i)
-    return True, f"frames {checked}: {len(bands)} row bands each bit-identical to the oracle"
+    return True, f"frames {checked}: {nb} row bands each bit-identical to the oracle"
 
 
-def main():
-    args = parse_args()
+def pmc_traffic(fmt_name, W, H, mode):
+    """HBM bytes per FRAME from the committed PMC profile for this surface format / frame size / launch mode, or None.
+    NOT measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc.sh + tools/parse_pmc.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            prof = json.load(fh)
+        for ent in prof.get("entries", []):
+            if ent.get("format") == fmt_name and list(ent.get("frame", [])) == [W, H] and ent.get("mode") == mode:
+                return ent["hbm_bytes_per_frame"], (f"profiles/pmc_traffic.json [{fmt_name}, {W}x{H}, {mode}] (rocprofv3 PMC "
+                                                    f"passes of {prof.get('tag', 'a committed profile')}), not measured by this run")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform"):
+    """Synthetic frames generated on the device, keyed by (seed, global frame index = first_index + f * stride)."""
+    cfas, params = [], []
+    for f in range(F):
+        gidx = first_index + f * stride
+        g = torch.Generator(device=dev)
+        g.manual_seed(SEED + gidx)
+        if data == "uniform":
+            cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
+        else:                                             # a diagonal ramp whose slope and offset vary per frame, +-1 % noise
+            yy = torch.arange(H, device=dev, dtype=torch.float32)[:, None] / H
+            xx = torch.arange(W, device=dev, dtype=torch.float32)[None, :] / W
+            a = 0.25 + 0.5 * ((gidx * 37) % 16) / 16.0
+            ramp = (a * xx + (1.0 - a) * yy) * 3600.0 + 200.0
+            noise = (torch.rand((H, W), generator=g, device=dev) - 0.5) * 2.0 * 40.96
+            cfas.append((ramp + noise).clamp_(0, 4095).to(torch.int16))
+            del yy, xx, ramp, noise
+        params.append(ra.EditParams.random(np.random.default_rng([SEED, gidx])))
+    return cfas, params
+
+
+def swapped_halves(params):
+    """The same stacks, the two halves of the batch exchanged: different descriptors, identical total arithmetic."""
+    n = len(params)
+    return [params[(i + n // 2) % n] for i in range(n)] if n > 1 else list(params)
+
+
+def workload_label(W, H, world, F):
+    if (W, H) == (6016, 4016):
+        return "BASELINE configs[2]" if world == 1 else f"BASELINE configs[3] ({F} frames per GPU)"
+    if (W, H) == (11648, 8736):
+        return "BASELINE configs[4] shape (100 MP; per GPU)"
+    return "custom frame size"
+
+
+def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, verified_note, host_note, descriptors_note):
+    total_px = float(world) * F * W * H * args.steps
+    launches = args.steps * lpc
+    launch_us = dev_ms * 1e3 / launches                    # avg fused-launch period incl. gaps and folds
+    frame_us = dev_ms * 1e3 / (args.steps * F)
+    alg_bytes = BYTES_PER_PX[args.format] * W * H * F / lpc
+    achieved = alg_bytes / (launch_us * 1e-6) / 1e9        # GB/s
+    multi = lpc < F * max(1, args.row_bands)
+    per_frame, traffic_source = pmc_traffic(args.format, W, H, "multi" if multi else "per_frame")
+    traffic = int(per_frame * F / lpc) if per_frame is not None else None       # per launch, like `achieved`
+    return {
+        "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
+        "value": round(total_px / 1e6 / elapsed, 1),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",                                    # the arithmetic type of the path for EVERY surface format
+        "surface_dtype": args.format,                      # what is stored (`--format`)
+        "data": "synthetic" if args.data == "uniform" else "synthetic (gradient + 1 % noise)",
+        "verified": verified,
+        "verified_note": verified_note,
+        "config": {
+            "workload": f"{workload_label(W, H, world, F)}: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
+                        f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'off' if args.no_hist else 'on'}, "
+                        f"{args.math} f32 arithmetic",
+            "frames_per_gpu": F, "width": W, "height": H, "surface": f"rgba_{args.format}",
+            "row_bands": args.row_bands, "out_ring": ring_len, "math_mode": args.math, "launches_per_step": lpc,
+            "host": host_note, "descriptors": descriptors_note,
+            "parallelism": f"frames sharded round-robin over {world} GPU(s); RCCL all-reduce of the u64[768] histogram only",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_source": traffic_source,
+            "kernel": "rd_develop_batch" if multi else "rd_develop_quads",
+            "launch_us": round(launch_us, 2), "frames_per_launch": round(F / lpc, 3), "us_per_frame": round(frame_us, 2),
+            "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
+                              "includes inter-launch gaps, descriptor uploads and the histogram folds (conservative)",
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+        },
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+# extra_configs (N = 1): the other BASELINE configurations, in the driver-timed record
+# ------------------------------------------------------------------------------------------------
+def roofline_of(fmt_name, W, H, us_per_frame, mode, kernel):
+    alg = BYTES_PER_PX[fmt_name] * W * H
+    ach = alg / (us_per_frame * 1e-6) / 1e9
+    per_frame, src = pmc_traffic(fmt_name, W, H, mode)
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "traffic": int(per_frame) if per_frame is not None else None, "traffic_source": src,
+            "traffic_unit": "HBM bytes per frame", "kernel": kernel, "algorithmic_bytes_per_frame": alg}
+
+
+def extra_single_frame(torch, np, ra, dev, dev_index, cfa_t, p, stream, iters=60):
+    """BASELINE configs[1]: ONE 24 MP frame, full 10-slider develop, f32 surface + fused histogram: rd_render_device
+    (one fused launch + the histogram fold) + synchronise per iteration -- the latency an interactive caller sees."""
+    import statistics
+    H, W = cfa_t.shape
+    out = torch.empty(H * W * 16, dtype=torch.uint8, device=dev)
+    hist = torch.zeros(768, dtype=torch.int32, device=dev)
+    pipe = ra.RenderPipeline.from_device(1, cfa_t.data_ptr(), W, H, p, WB, CM, device=dev_index)
+    host_us, kern_us = [], []
+    with torch.cuda.stream(stream):
+        for it in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            pipe.render_device(W, H, ra.FMT_RGBA_F32, out.data_ptr(), hist.data_ptr(), stream.cuda_stream)
+            e1.record(stream)
+            stream.synchronize()
+            host_us.append((time.perf_counter() - t0) * 1e6)
+            kern_us.append(e0.elapsed_time(e1) * 1e3)
+    host_us, kern_us = host_us[10:], kern_us[10:]
+    med, kmed = statistics.median(host_us), statistics.median(kern_us)
+    ok, info = check_bands("f32", W, H, cfa_t, p, out, "strict", "single frame")
+    ok = ok and int(hist.sum().item()) == 3 * W * H
+    pipe.close()
+    return {"config": "BASELINE configs[1]: single 24 MP RGGB frame, full 10-slider develop, f32 surface + fused histogram, "
+                      "rd_render_device + synchronise per iteration",
+            "iterations": len(host_us), "ms": round(med / 1e3, 5), "ms_min": round(min(host_us) / 1e3, 5),
+            "MP_per_s": round(W * H / med, 1), "kernel_us": round(kmed, 2),
+            "latency_note": "ms = median host-side time of launch + histogram fold + stream synchronise; kernel_us = median HIP-event "
+                            "time of the same enqueue (the roofline figure uses it)",
+            "roofline": roofline_of("f32", W, H, kmed, "per_frame", "rd_develop_quads"),
+            "verified": bool(ok), "verified_note": f"{info} row bands bit-identical to the oracle, histogram counts every pixel" if ok else str(info)}
+
+
+def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, ring_n, row_bands, steps, stream, label, kernel_mode):
+    """A batch workload on another surface format / frame size, timed like the headline (HIP events, descriptors alternate)."""
+    fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8}[fmt_name]
+    bpp = ra.BYTES_PER_PIXEL[fmt]
+    F = len(cfas)
+    ring = [torch.empty(H * W * bpp, dtype=torch.uint8, device=dev) for _ in range(ring_n)]
+    hist = torch.zeros(768, dtype=torch.int64, device=dev)
+    be = ra.BatchExporter(dev_index, W, H, fmt, True)
+    variants = [params, swapped_halves(params)]
+    arrays = [be.make_frames([c.data_ptr() for c in cfas], [ring[i % ring_n].data_ptr() for i in range(F)], v, WB, CM)
+              for v in variants]
+    with torch.cuda.stream(stream):
+        k = 0
+        for _ in range(2):
+            be.develop(arrays[k % 2], row_bands=row_bands, stream=stream.cuda_stream); k += 1
+        be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            be.develop(arrays[k % 2], row_bands=row_bands, stream=stream.cuda_stream); k += 1
+            be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+        stream.synchronize()
+    ms = e0.elapsed_time(e1)
+    us = ms * 1e3 / (steps * F)
+    lpc = max(1, be.last_launch_count())
+    ok = int(hist.sum().item()) == 3 * F * W * H
+    note = "histogram does not count every pixel"
+    if ok:
+        ok, note = verify_outputs(fmt_name, W, H, cfas, variants[(k - 1) % 2], ring, F, "strict")
+    be.close()
+    del ring
+    return {"config": label, "frames": F, "steps": steps, "ms": round(ms / steps, 4), "us_per_frame": round(us, 2),
+            "MP_per_s": round(W * H / us, 1), "launches_per_step": lpc, "out_ring": ring_n, "row_bands": row_bands,
+            "roofline": roofline_of(fmt_name, W, H, us, kernel_mode, "rd_develop_batch"),
+            "verified": bool(ok), "verified_note": note}
+
+
+def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream):
+    out = {}
+    t0 = time.perf_counter()
+    out["single_frame_f32"] = extra_single_frame(torch, np, ra, dev, dev_index, cfas[0], params[0], stream)
+    n8 = min(64, len(cfas))
+    out["batch_rgba8"] = extra_batch(torch, np, ra, dev, dev_index, "u8", cfas[:n8], params[:n8], 6016, 4016, 32, 1, 5, stream,
+                                     f"the reference's own surface (Rgba8Unorm, pipeline.rs:322) on the batch workload: {n8} x 6016x4016, "
+                                     "randomised stacks, fused histogram, strict f32 arithmetic", "multi")
+    W5, H5 = 11648, 8736
+    c5, p5 = make_batch(torch, np, ra, dev, W5, H5, 8, 1 << 20, 1)
+    out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3, stream,
+                                           "BASELINE configs[4] shape on one GPU: 8 x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
+                                           "row_bands 8, randomised stacks, fused histogram, strict f32 arithmetic", "multi")
+    del c5
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# --host ranks: one process per GPU (the driver's contract)
+# ------------------------------------------------------------------------------------------------
+def run_ranks(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     # RCCL / device-tensor sharing across processes needs dmabuf IPC on this pool's host driver (already exported by the
     # image; kept here so that a bare `python -m torch.distributed.run ... bench.py` works from any shell)
@@ -202,35 +490,22 @@ def main():
     bpp_out = ra.BYTES_PER_PIXEL[fmt]
     with_hist = not args.no_hist
 
-    # ---- synthetic batch, generated on the device, keyed by (seed, global frame index) ------------
-    cfas, params = [], []
-    for f in range(F):
-        gidx = rank + f * world                           # frame i -> rank i mod N
-        g = torch.Generator(device=dev)
-        g.manual_seed(SEED + gidx)
-        if args.data == "uniform":
-            cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
-        else:                                             # a diagonal ramp whose slope and offset vary per frame, +-1 % noise
-            yy = torch.arange(H, device=dev, dtype=torch.float32)[:, None] / H
-            xx = torch.arange(W, device=dev, dtype=torch.float32)[None, :] / W
-            a = 0.25 + 0.5 * ((gidx * 37) % 16) / 16.0
-            ramp = (a * xx + (1.0 - a) * yy) * 3600.0 + 200.0
-            noise = (torch.rand((H, W), generator=g, device=dev) - 0.5) * 2.0 * 40.96
-            cfas.append((ramp + noise).clamp_(0, 4095).to(torch.int16))
-            del yy, xx, ramp, noise
-        params.append(ra.EditParams.random(np.random.default_rng([SEED, gidx])))
+    cfas, params = make_batch(torch, np, ra, dev, W, H, F, rank, world, args.data)     # frame i -> rank i mod N
     ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
     math_mode = ra.MATH_CONTRACTED if args.math == "contracted" else ra.MATH_STRICT
     be = ra.BatchExporter(dev_index, W, H, fmt, with_hist, math_mode=math_mode)
-    frames = be.make_frames([c.data_ptr() for c in cfas], [ring[i % len(ring)].data_ptr() for i in range(F)],
-                            params, WB, CM)
+    variants = [params] if args.static_descriptors else [params, swapped_halves(params)]
+    arrays = [be.make_frames([c.data_ptr() for c in cfas], [ring[i % len(ring)].data_ptr() for i in range(F)], v, WB, CM)
+              for v in variants]
     stream = torch.cuda.Stream(device=dev)
+    nstep = [0]
 
     def step():
-        be.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
+        be.develop(arrays[nstep[0] % len(arrays)], row_bands=args.row_bands, stream=stream.cuda_stream)
+        nstep[0] += 1
         if with_hist:
             be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
             if world > 1:
@@ -261,7 +536,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_px = float(world) * F * W * H * args.steps
     if with_hist:                                          # sanity: the global histogram counts every pixel
         got = int(hist.sum().item())
         assert got == 3 * world * F * W * H, f"histogram sum {got} != {3 * world * F * W * H}"
@@ -269,7 +543,8 @@ def main():
     verified, verified_note = None, "not checked"
     if rank == 0:                                          # outside the timed region
         try:
-            verified, verified_note = verify_outputs(ra, args.format, W, H, cfas, params, ring, F, args.row_bands, args.math)
+            last = variants[(nstep[0] - 1) % len(variants)]
+            verified, verified_note = verify_outputs(args.format, W, H, cfas, last, ring, F, args.math)
         except Exception as e:  # noqa: BLE001  (oracle not built / not shipped: say so, do not claim)
             verified, verified_note = None, f"oracle check unavailable: {e}"
 
@@ -277,81 +552,23 @@ def main():
     # RD_BATCH_PERSISTENT=0 gives one launch per frame / row band).  Algorithmic bytes per launch = SURVEY 8(d)'s
     # per-pixel figure x the pixels one launch processes.
     lpc = max(1, be.last_launch_count())
-    launches = args.steps * lpc
-    launch_us = dev_ms * 1e3 / launches                    # avg fused-launch period incl. gaps and folds
-    frame_us = dev_ms * 1e3 / (args.steps * F)
-    alg_bytes = BYTES_PER_PX[args.format] * W * H * F / lpc
-    achieved = alg_bytes / (launch_us * 1e-6) / 1e9        # GB/s
-    # HBM bytes per launch: NOT measured by this run.  It is the PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # passes, tools/gpu_pmc.sh + tools/parse_pmc.py) of the committed profile for this surface format, when the
-    # profile was taken on the same frame size / band count; otherwise null.
-    traffic, traffic_source = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            prof = json.load(fh)
-        mode = "multi" if lpc < F * max(1, args.row_bands) else "per_frame"
-        for ent in prof.get("entries", []):
-            if ent.get("format") == args.format and list(ent.get("frame", [])) == [W, H] and ent.get("mode") == mode:
-                traffic = int(ent["hbm_bytes_per_frame"] * F / lpc)             # per launch, like `achieved`
-                traffic_source = (f"profiles/pmc_traffic.json [{args.format}, {W}x{H}, {mode}] (rocprofv3 PMC passes of "
-                                  f"{prof.get('tag', 'a committed profile')}), not measured by this run")
-                break
-    except (OSError, ValueError):
-        pass
-
-    if (W, H) == (6016, 4016):
-        cfg_label = "BASELINE configs[2]" if world == 1 else f"BASELINE configs[3] ({F} frames per GPU)"
-    elif (W, H) == (11648, 8736):
-        cfg_label = "BASELINE configs[4] shape (100 MP; per GPU)"
-    else:
-        cfg_label = "custom frame size"
-    result = {
-        "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
-        "value": round(total_px / 1e6 / elapsed, 1),
-        "unit": "MP/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",                                    # the arithmetic type of the path for EVERY surface format
-        "surface_dtype": {"f32": "f32", "f16": "f16", "u8": "u8"}[args.format],   # what is stored (`--format`)
-        "data": "synthetic" if args.data == "uniform" else "synthetic (gradient + 1 % noise)",
-        "verified": verified,
-        "verified_note": verified_note,
-        "config": {
-            "workload": f"{cfg_label}: batch {F} x {W}x{H} synthetic RGGB u16 per GPU, randomised "
-                        f"10-slider stacks, RGBA-{args.format} surface, fused histogram={'on' if with_hist else 'off'}, "
-                        f"{args.math} f32 arithmetic",
-            "frames_per_gpu": F, "width": W, "height": H, "surface": f"rgba_{args.format}",
-            "row_bands": args.row_bands, "out_ring": len(ring), "math_mode": args.math, "launches_per_step": lpc,
-            "parallelism": f"frames sharded round-robin over {world} GPU(s); RCCL all-reduce of i64[768] histogram only",
-        },
-        "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "traffic_source": traffic_source,
-            "kernel": "rd_develop_batch" if lpc < F * max(1, args.row_bands) else "rd_develop_quads",
-            "launch_us": round(launch_us, 2), "frames_per_launch": round(F / lpc, 3), "us_per_frame": round(frame_us, 2),
-            "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
-                              "includes inter-launch gaps and the histogram folds (conservative)",
-            "algorithmic_bytes_per_launch": int(alg_bytes),
-        },
-    }
+    result = result_line(args, world, F, W, H, elapsed, dev_ms, lpc, len(ring), verified, verified_note,
+                         "one process per GPU (torch.distributed, backend " + (backend if world > 1 else "none: single rank") + ")",
+                         "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
+                         "steps alternate between two frame arrays (slider stacks of the two batch halves swapped): every step "
+                         "uploads its descriptors")
     if world == 1 and not args.no_alt_math:
         # Reported-only: the same workload in the other arithmetic, 5 steps.
         other = "contracted" if args.math == "strict" else "strict"
         be2 = ra.BatchExporter(dev_index, W, H, fmt, with_hist,
                                math_mode=ra.MATH_CONTRACTED if other == "contracted" else ra.MATH_STRICT)
         with torch.cuda.stream(stream):
-            be2.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
+            be2.develop(arrays[0], row_bands=args.row_bands, stream=stream.cuda_stream)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            for _ in range(5):
-                be2.develop(frames, row_bands=args.row_bands, stream=stream.cuda_stream)
+            for k in range(5):
+                be2.develop(arrays[(k + 1) % len(arrays)], row_bands=args.row_bands, stream=stream.cuda_stream)
                 if with_hist:
                     be2.histogram(hist.data_ptr(), stream=stream.cuda_stream)
             e1.record(stream)
@@ -362,6 +579,12 @@ def main():
                               "us_per_frame": round(us, 2), "achieved_GBps": round(ach, 1),
                               "frac": round(ach / HBM_PEAK_GBPS, 4)}
         be2.close()
+    if rank == 0 and world == 1 and not args.no_extra and (W, H) == (6016, 4016) and args.data == "uniform":
+        del ring
+        try:
+            result["extra_configs"] = extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream)
+        except Exception as e:  # noqa: BLE001  (never lose the headline line to an extra)
+            result["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
     if rank == 0:
@@ -370,6 +593,114 @@ def main():
     if world > 1:
         dist.barrier()                                     # rank 0 spent a second on the oracle check: leave together
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# --host node: ONE process, all GPUs through rd_node_batch_* 
+# ------------------------------------------------------------------------------------------------
+def run_node(args):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+    import raweditor_amd as ra
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    N = args.gpus
+    ndev = torch.cuda.device_count()
+    if N > ndev:
+        # a rehearsal on a smaller box: a device listed several times; librawdev accepts that only with RD_NODE_REDUCE=host
+        # (histograms folded on the host) or with the test stand-in for librccl
+        if os.environ.get("RD_NODE_REDUCE") != "host" and not os.environ.get("RAWDEV_RCCL_LIB"):
+            sys.exit(f"--host node --gpus {N}: only {ndev} device(s) visible (RD_NODE_REDUCE=host rehearses N > devices on one GPU)")
+    devices = [d % ndev for d in range(N)]
+    W, H, F = args.width, args.height, args.frames
+    fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8}[args.format]
+    bpp_out = ra.BYTES_PER_PIXEL[fmt]
+    with_hist = not args.no_hist
+    math_mode = ra.MATH_CONTRACTED if args.math == "contracted" else ra.MATH_STRICT
+
+    # frame i of the call belongs to devices[i mod N]: F frames per device, interleaved
+    per_dev = []
+    for r, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        cfas, params = make_batch(torch, np, ra, dev, W, H, F, r, N, args.data)
+        ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
+        per_dev.append((cfas, params, ring))
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    nb = ra.NodeBatch(devices, W, H, fmt, with_hist, math_mode=math_mode)
+
+    def frame_array(swap):
+        cp, op, pp = [], [], []
+        for i in range(F * N):
+            r, f = i % N, i // N
+            cfas, params, ring = per_dev[r]
+            pv = swapped_halves(params) if swap else params
+            cp.append(cfas[f].data_ptr()); op.append(ring[f % len(ring)].data_ptr()); pp.append(pv[f])
+        return ra.BatchExporter.make_frames(cp, op, pp, WB, CM)
+
+    arrays = [frame_array(False)] if args.static_descriptors else [frame_array(False), frame_array(True)]
+    nstep = [0]
+    hist = None
+
+    def step():
+        nonlocal hist
+        nb.develop(arrays[nstep[0] % len(arrays)], row_bands=args.row_bands)
+        nstep[0] += 1
+        if with_hist:
+            hist = nb.histogram()                          # per-device fold + all-reduce + read-back; synchronises
+        # without a histogram the steps queue up on the devices' streams; the region ends with nb.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    nb.synchronize()
+    s0 = torch.cuda.ExternalStream(nb.stream(0), device=torch.device("cuda", devices[0]))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(s0)
+    for _ in range(args.steps):
+        step()
+    ev1.record(s0)
+    nb.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                         # HIP events on device 0's launch stream
+
+    if with_hist:
+        got = int(hist.sum())
+        assert got == 3 * N * F * W * H, f"histogram sum {got} != {3 * N * F * W * H}"
+    verified, verified_note = None, "not checked"
+    try:
+        cfas, params, ring = per_dev[0]
+        last = params if (len(arrays) == 1 or (nstep[0] - 1) % 2 == 0) else swapped_halves(params)
+        verified, verified_note = verify_outputs(args.format, W, H, cfas, last, ring, F, args.math)
+    except Exception as e:  # noqa: BLE001
+        verified, verified_note = None, f"oracle check unavailable: {e}"
+    lpc = max(1, nb.last_launch_count(0))
+    dup = len(set(devices)) < N
+    result = result_line(args, N, F, W, H, elapsed, dev_ms, lpc, len(per_dev[0][2]), verified, verified_note,
+                         f"ONE process, rd_node_batch_* over devices {devices} (one rd_batch + stream + host thread per device); "
+                         f"histogram reduction: {nb.reduce_kind()}; each step = develop + histogram (synchronises)" +
+                         ("; REHEARSAL: a device is listed more than once, the ranks share one GPU" if dup else ""),
+                         "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
+                         "steps alternate between two frame arrays: every step uploads its descriptors")
+    if N == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
+    print(json.dumps(result), flush=True)
+    nb.close()
+
+
+def main():
+    args = parse_args()
+    in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.host == "node":
+        if in_launcher and int(os.environ["WORLD_SIZE"]) > 1:
+            sys.exit("--host node is ONE process for all GPUs: start it without torch.distributed.run")
+        return run_node(args)
+    if not in_launcher and args.gpus > 1:
+        # the driver's N = 1 shape of the command, with N > 1: become the launcher.  Nothing has touched the GPU, torch
+        # or HIP in this process; the ranks are fresh children (never an exec of this process).
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    return run_ranks(args)
 
 
 if __name__ == "__main__":

@@ -219,7 +219,8 @@ int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);
  * first use, and only when n_devices > 1); with one device there is no communicator.
  * Environment: RD_NODE_REDUCE=host folds the per-device histograms on the host instead (and then accepts a device
  * listed twice: a rehearsal of N > 1 on a one-GPU box); RD_NODE_REDUCE=rccl builds a communicator even for one device;
- * RAWDEV_RCCL_LIB names the library file. */
+ * RAWDEV_RCCL_LIB names the library file (it wins over a copy the process has already mapped; when it names the test
+ * stand-in tests/cpp/rccl_standin.cpp, a device may also be listed twice). */
 typedef struct rd_node_batch rd_node_batch;
 int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
                          uint32_t with_histogram, rd_node_batch **out);
@@ -233,6 +234,12 @@ int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_fr
  * (R[256] G[256] B[256], u64).  Returns when every device has finished; resets the accumulators. */
 int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768]);
 int rd_node_batch_synchronize(rd_node_batch *nb);
+/* Measurement aids (bench.py --host node): the hipStream_t devices[index]'s share is enqueued on (record events there),
+ * the fused launches its share of the last develop call took, and how the histogram is reduced (0 = one device, no
+ * exchange; 1 = RCCL all-reduce; 2 = host fold, RD_NODE_REDUCE=host). */
+void *rd_node_batch_stream(rd_node_batch *nb, uint32_t index);
+uint32_t rd_node_batch_last_launch_count(const rd_node_batch *nb, uint32_t index);
+int rd_node_batch_reduce_kind(const rd_node_batch *nb);
 
 /* ---- export feed (the step after the path) ----------------------------------- */
 /* The GPU half of export_image_async (main.rs:1744-1799) for a stream of frames: render_full_res_to_bytes'
@@ -274,7 +281,11 @@ int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint
 /* Lossless JPEG (ITU-T T.81 SOF3: Huffman, predictors 1-7, 1-4 interleaved components, precision 2-16, restart
  * intervals) as found in the tiles / strips of compressed DNGs (TIFF Compression = 7).  The reference decodes RAW files
  * with the un-vendored `rawloader` crate (raw/loader.rs:50-54): no parity claim against it; lossless JPEG is exact by
- * construction.  dst receives height * width * components samples, row-major, components interleaved. */
+ * construction.  dst receives height * width * components samples, row-major, components interleaved.
+ * The frame's dimensions are written as soon as its headers have been walked -- also when the call then fails because
+ * dst_capacity_samples is too small, so a first call with dst = NULL and capacity 0 sizes the buffer (a stream that
+ * fails earlier leaves them 0).  A stream that ends before its declared frame fails at the row where it ran dry; a
+ * restart interval that is not a whole number of lines is refused. */
 int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_capacity_samples, uint32_t *width,
                     uint32_t *height, uint32_t *components, uint32_t *precision);
 
@@ -294,6 +305,9 @@ int rd_stream_destroy(int device, void *stream);
  * the stream must re-zero them and come out right. */
 int rd_debug_poison_scheduler(rd_pipeline *p, void *stream);
 uint32_t rd_debug_scheduler_entries(rd_pipeline *p);   /* streams this pipeline currently keeps state for (<= 16) */
+/* devices[index]'s own 768 x u64 histogram buffer as the last rd_node_batch_histogram left it (after an all-reduce every
+ * device holds the global sum). */
+int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768]);
 
 #ifdef __cplusplus
 }

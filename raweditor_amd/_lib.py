@@ -85,6 +85,9 @@ PROTOTYPES = {
     "rd_node_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32]),
     "rd_node_batch_histogram": (_I, [_VP, _VP]),
     "rd_node_batch_synchronize": (_I, [_VP]),
+    "rd_node_batch_stream": (_VP, [_VP, _U32]),
+    "rd_node_batch_last_launch_count": (_U32, [_VP, _U32]),
+    "rd_node_batch_reduce_kind": (_I, [_VP]),
     "rd_exporter_create": (_I, [_I, _U32, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),
     "rd_exporter_destroy": (None, [_VP]),
     "rd_exporter_submit": (_I, [_VP, C.POINTER(RdFrame), C.POINTER(_U32)]),
@@ -105,6 +108,7 @@ PROTOTYPES = {
     "rd_stream_destroy": (_I, [_I, _VP]),
     "rd_debug_poison_scheduler": (_I, [_VP, _VP]),
     "rd_debug_scheduler_entries": (_U32, [_VP]),
+    "rd_debug_node_histogram_of": (_I, [_VP, _U32, _VP]),
 }
 
 _lib = None

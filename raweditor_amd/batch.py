@@ -67,6 +67,18 @@ class NodeBatch:
     def synchronize(self) -> None:
         check(_lib.lib().rd_node_batch_synchronize(self._h))
 
+    def stream(self, index: int) -> int:
+        """The hipStream_t (as int) devices[index]'s share is enqueued on (measurement aid: record events there)."""
+        return int(_lib.lib().rd_node_batch_stream(self._h, int(index)) or 0)
+
+    def last_launch_count(self, index: int = 0) -> int:
+        return int(_lib.lib().rd_node_batch_last_launch_count(self._h, int(index)))
+
+    REDUCE_KINDS = {0: "none (one device)", 1: "rccl all-reduce", 2: "host fold (RD_NODE_REDUCE=host)"}
+
+    def reduce_kind(self) -> str:
+        return self.REDUCE_KINDS.get(int(_lib.lib().rd_node_batch_reduce_kind(self._h)), "?")
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             _lib.lib().rd_node_batch_destroy(self._h)

@@ -1002,6 +1002,7 @@ struct rd_rccl_api {
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
     bool ok = false;
+    bool standin = false;                        // the test stand-in, not RCCL: ranks may then share a device
 };
 constexpr int RD_NCCL_UINT64 = 5, RD_NCCL_SUM = 0;           // rccl.h: ncclUint64, ncclSum
 
@@ -1011,8 +1012,13 @@ rd_rccl_api &rd_rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char *env = getenv("RAWDEV_RCCL_LIB");
-        const char *names[] = { env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        // a copy that is already mapped (a PyTorch process has its own) serves us too: one RCCL per process
+        const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        // an explicitly named library wins (RAWDEV_RCCL_LIB); otherwise a copy that is already mapped (a PyTorch process
+        // has its own) serves us too: one RCCL per process
+        if (env && *env) {
+            api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
+        }
         for (const char *n : { "librccl.so.1", "librccl.so" })
             if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char *n : names)
@@ -1026,6 +1032,8 @@ rd_rccl_api &rd_rccl()
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
         api.ok = api.error.empty();
+        // tests/cpp/rccl_standin.cpp (a host-memory all-reduce for one-GPU rehearsals of the grouped call sequence) says so
+        api.standin = api.ok && dlsym(api.handle, "rawdev_rccl_standin") != nullptr;
     });
     return api;
 }
@@ -1082,7 +1090,9 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
         for (uint32_t b = a + 1; b < n_devices; ++b) dup = dup || devices[a] == devices[b];
     const char *env = getenv("RD_NODE_REDUCE");              // "host": fold on the host; "rccl": a communicator even for N = 1
     const bool want_host = env && !strcmp(env, "host"), want_rccl = env && !strcmp(env, "rccl");
-    if (dup && !want_host)
+    // A device listed twice is a rehearsal of N > 1 on a one-GPU box: allowed with the host fold, or when RAWDEV_RCCL_LIB
+    // names the test stand-in (real RCCL wants one rank per device).
+    if (dup && !want_host && !(getenv("RAWDEV_RCCL_LIB") && rd_rccl().standin))
         return rd_fail(RD_ERR_INVALID_ARG, "device list holds a device twice (RCCL wants one rank per device; RD_NODE_REDUCE=host "
                                            "allows it for rehearsals on a one-GPU box)");
     rd_node_batch *nb = new (std::nothrow) rd_node_batch;
@@ -1152,6 +1162,30 @@ extern "C" int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, 
         const std::vector<rd_frame> &v = nb->share[d];
         return v.empty() ? (int)RD_OK : rd_batch_develop(nb->batches[d], v.data(), v.size(), row_bands, nb->streams[d]);
     });
+}
+
+extern "C" void *rd_node_batch_stream(rd_node_batch *nb, uint32_t index)
+{
+    return nb && index < nb->n ? (void *)nb->streams[index] : nullptr;
+}
+
+extern "C" uint32_t rd_node_batch_last_launch_count(const rd_node_batch *nb, uint32_t index)
+{
+    return nb && index < nb->n ? rd_batch_last_launch_count(nb->batches[index]) : 0u;
+}
+
+extern "C" int rd_node_batch_reduce_kind(const rd_node_batch *nb) { return nb ? nb->reduce : -1; }
+
+// test hook: what devices[index]'s 768 x u64 buffer holds after the last rd_node_batch_histogram (after an all-reduce
+// every device must hold the global sum, not only the one the call reads back)
+extern "C" int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768])
+{
+    if (!nb || !hist || index >= nb->n || !nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "rd_debug_node_histogram_of: bad argument");
+    rd_devguard g(nb->devices[index]);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[index]);
+    RD_HIP(hipMemcpyAsync(hist, nb->hist_dev[index], 768 * sizeof(uint64_t), hipMemcpyDeviceToHost, nb->streams[index]));
+    RD_HIP(hipStreamSynchronize(nb->streams[index]));
+    return RD_OK;
 }
 
 extern "C" int rd_node_batch_synchronize(rd_node_batch *nb)
@@ -1470,7 +1504,11 @@ extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_
 extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_capacity_samples, uint32_t *width,
                                uint32_t *height, uint32_t *components, uint32_t *precision)
 {
-    if (!src || !dst) return rd_fail(RD_ERR_INVALID_ARG, "rd_ljpeg_decode: NULL argument");
+    if (!src || (!dst && dst_capacity_samples)) return rd_fail(RD_ERR_INVALID_ARG, "rd_ljpeg_decode: NULL argument");
+    if (width) *width = 0;
+    if (height) *height = 0;
+    if (components) *components = 0;
+    if (precision) *precision = 0;
     const int rc = rd_ljpeg::decode(src, len, dst, dst_capacity_samples, width, height, components, precision);
     switch (rc) {
     case rd_ljpeg::OK: return RD_OK;

@@ -29,7 +29,8 @@ struct bits {
     const uint8_t *p, *end;
     uint64_t acc = 0;
     int n = 0;
-    int injected = 0;                        // zero bits appended after a marker or the end of the input
+    int64_t injected = 0;                    // zero bits appended after a marker or the end of the input (64-bit: a
+                                             // damaged stream may ask for more than 2^31 of them before a row check)
     bool hit_marker = false;
     void fill()
     {
@@ -156,12 +157,15 @@ inline int decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_cap,
             }
             const int pred = d[1 + 2 * N], pt = d[3 + 2 * N] & 15;
             if (pred < 1 || pred > 7 || (uint32_t)pt >= P) return ERR_UNSUPPORTED;
+            // a restart interval is a whole number of lines (T.81 H.1.2.1 as DNG writers use it): anything else would be
+            // predicted wrongly below (first sample after RSTn from Ra instead of 2^(P-Pt-1)) without any error
+            if (restart && restart % W) return ERR_UNSUPPORTED;
             const size_t total = (size_t)W * H * N;
-            if (total > dst_cap) return ERR_SIZE;
-            if (w) *w = W;
-            if (h) *h = H;
+            if (w) *w = W;                                                     // reported BEFORE the capacity check, so a caller
+            if (h) *h = H;                                                     // can ask for the frame size with capacity 0
             if (nc) *nc = N;
             if (prec) *prec = P;
+            if (total > dst_cap) return ERR_SIZE;
             bits b;
             b.p = src + pos + 2 + seg;
             b.end = src + len;
@@ -210,6 +214,9 @@ inline int decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_cap,
                     if (restart) --until_restart;
                     if (x == W - 1) fresh = false;                             // "fresh" lasts for one line
                 }
+                // a truncated stream is refused after the row in which it ran dry, not decoded to the end of the declared
+                // frame out of injected zero bits
+                if (b.overran()) return ERR_TRUNCATED;
             }
             if (b.overran()) return ERR_TRUNCATED;                             // the entropy-coded segment ended before the image did
             if (pt) for (size_t i = 0; i < total; ++i) dst[i] = (uint16_t)(dst[i] << pt);

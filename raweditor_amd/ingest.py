@@ -76,13 +76,40 @@ def samples_to_u16(values: np.ndarray) -> np.ndarray:
     return values.astype(np.uint16, copy=False)
 
 
+_UNPACK_GROUP = {10: (5, 4), 12: (3, 2), 14: (7, 4)}      # bits -> (bytes, samples) of the smallest whole-byte group
+_UNPACK_CHUNK_BYTES = 8 << 20                              # packed bytes per pass: bounds the temporaries (~6x that)
+
+
 def unpack_bits(rows: np.ndarray, width: int, bits: int) -> np.ndarray:
-    """(n_rows, row_bytes) uint8, samples of `bits` bits packed MSB first -> (n_rows, width) uint16."""
+    """(n_rows, row_bytes) uint8, samples of `bits` bits packed MSB first -> (n_rows, width) uint16.
+    Whole-byte groups (5 bytes = 4 x 10 bit, 3 = 2 x 12, 7 = 4 x 14) are gathered into one u64 and split with shifts, a
+    bounded block of rows at a time: a 24 MP 12-bit strip needs tens of MB of temporaries, not gigabytes."""
     if bits == 8:
         return rows[:, :width].astype(np.uint16)
-    b = np.unpackbits(rows, axis=1)[:, :width * bits].reshape(rows.shape[0], width, bits)
-    weights = (1 << np.arange(bits - 1, -1, -1)).astype(np.uint32)
-    return (b.astype(np.uint32) * weights).sum(axis=2).astype(np.uint16)
+    if bits == 16:
+        return (rows[:, 0:2 * width:2].astype(np.uint16) << 8) | rows[:, 1:2 * width:2]
+    if bits not in _UNPACK_GROUP:
+        raise ValueError(f"unsupported packed sample width {bits}")
+    gb, gs = _UNPACK_GROUP[bits]
+    n_rows, row_bytes = rows.shape
+    groups = (width + gs - 1) // gs
+    need = groups * gb
+    out = np.empty((n_rows, width), np.uint16)
+    step = max(1, _UNPACK_CHUNK_BYTES // max(1, need))
+    mask = np.uint64((1 << bits) - 1)
+    for r0 in range(0, n_rows, step):
+        blk = rows[r0:r0 + step]
+        if row_bytes < need:                                 # the last group of a row may lack its padding bytes
+            blk = np.concatenate([blk, np.zeros((blk.shape[0], need - row_bytes), np.uint8)], axis=1)
+        g = blk[:, :need].reshape(blk.shape[0], groups, gb)
+        acc = np.zeros((blk.shape[0], groups), np.uint64)
+        for k in range(gb):
+            acc = (acc << np.uint64(8)) | g[:, :, k]
+        vals = np.empty((blk.shape[0], groups, gs), np.uint16)
+        for k in range(gs):
+            vals[:, :, k] = (acc >> np.uint64(bits * (gs - 1 - k))) & mask
+        out[r0:r0 + step] = vals.reshape(blk.shape[0], groups * gs)[:, :width]
+    return out
 
 
 def load_raw_u16(path: str, width: int, height: int, wb_coeffs: Sequence[float] = (),
@@ -98,8 +125,9 @@ def load_raw_u16(path: str, width: int, height: int, wb_coeffs: Sequence[float] 
 
 
 # ---- minimal TIFF / DNG ----------------------------------------------------------------------------------
-_TYPE_SIZE = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 7: 1, 8: 2, 9: 4, 10: 8, 11: 4, 12: 8}
-_TYPE_FMT = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 11: "f", 12: "d"}
+# TIFF field types; 13 = IFD (an offset, read like LONG: what many writers use for the SubIFDs tag 330)
+_TYPE_SIZE = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 7: 1, 8: 2, 9: 4, 10: 8, 11: 4, 12: 8, 13: 4}
+_TYPE_FMT = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 11: "f", 12: "d", 13: "I"}
 TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
 TAG_STRIP_OFFSETS, TAG_SPP, TAG_ROWS_PER_STRIP, TAG_STRIP_BYTES, TAG_SUBIFD = 273, 277, 278, 279, 330
 TAG_TILE_WIDTH, TAG_TILE_LENGTH, TAG_TILE_OFFSETS, TAG_TILE_BYTES = 322, 323, 324, 325
@@ -146,28 +174,36 @@ def _read_ifd(buf: bytes, off: int, e: str):
     return tags, nxt
 
 
-def ljpeg_decode(stream: bytes) -> np.ndarray:
+LJPEG_MAX_SAMPLES = 1 << 28          # 268 M samples (512 MiB of u16) per stream unless the caller knows the tile size
+
+
+def ljpeg_decode(stream: bytes, max_samples: Optional[int] = None) -> np.ndarray:
     """One lossless-JPEG stream (ITU-T T.81 SOF3) -> (height, width * components) uint16, through librawdev's host-side
-    decoder (rd_ljpeg_decode).  Errors carry the reference's "Failed to decode RAW" text."""
+    decoder (rd_ljpeg_decode).  Errors carry the reference's "Failed to decode RAW" text.
+    The stream is not trusted: the frame size comes from the decoder's own marker walk (a first call with capacity 0 --
+    not a byte search, which an APPn / COM payload could satisfy), and a frame that declares more than `max_samples`
+    samples (the TIFF tile / strip size when called from load_dng) is refused BEFORE anything is allocated; a stream that
+    ends early fails at the row where it ran dry."""
     import ctypes as C
     from . import _lib
     buf = bytes(stream)
     if len(buf) < 12 or buf[:2] != b"\xff\xd8":
         raise _decode_error("not a JPEG stream")
-    # the frame header says how many samples to expect: find SOF3 (0xFFC3) cheaply for the allocation
-    i = buf.find(b"\xff\xc3")
-    if i < 0 or i + 10 > len(buf):
-        raise _decode_error("no lossless-JPEG frame header (SOF3)")
-    h, w, nc = struct.unpack_from(">HH", buf, i + 5) + (buf[i + 9],)
-    n = int(h) * int(w) * int(nc)
-    if n <= 0 or n > (1 << 31):
-        raise _decode_error("implausible lossless-JPEG frame size")
-    out = np.empty(n, np.uint16)
+    limit = LJPEG_MAX_SAMPLES if max_samples is None else int(max_samples)
     dims = [C.c_uint32() for _ in range(4)]
     src = (C.c_uint8 * len(buf)).from_buffer_copy(buf)
-    rc = _lib.lib().rd_ljpeg_decode(src, len(buf), out.ctypes.data_as(C.c_void_p), n, *[C.byref(d) for d in dims])
+    L = _lib.lib()
+    rc = L.rd_ljpeg_decode(src, len(buf), None, 0, *[C.byref(d) for d in dims])      # sizes only: ends with "too small"
+    n = int(dims[0].value) * int(dims[1].value) * int(dims[2].value)
+    if n <= 0:                                               # the header walk itself failed (rc says why)
+        raise ValueError(L.rd_last_error().decode("utf-8", "replace") if rc != 0 else "Failed to decode RAW: empty frame")
+    if n > limit:
+        raise _decode_error(f"lossless-JPEG frame declares {dims[0].value}x{dims[1].value}x{dims[2].value} samples, "
+                            f"more than the {limit} its tile / strip can hold")
+    out = np.empty(n, np.uint16)
+    rc = L.rd_ljpeg_decode(src, len(buf), out.ctypes.data_as(C.c_void_p), n, *[C.byref(d) for d in dims])
     if rc != 0:
-        raise ValueError(_lib.lib().rd_last_error().decode("utf-8", "replace"))
+        raise ValueError(L.rd_last_error().decode("utf-8", "replace"))
     hh, ww = dims[1].value, dims[0].value * dims[2].value
     return out[:hh * ww].reshape(hh, ww)
 
@@ -281,7 +317,7 @@ def _read_ljpeg_image(buf: bytes, raw: dict):
         o, nbytes = int(offs[k]), int(sizes[k])
         if o + nbytes > len(buf) or nbytes < 4:
             raise _decode_error(f"tile {k} ({nbytes} bytes at {o}) is outside the file")
-        tile = ljpeg_decode(buf[o:o + nbytes])
+        tile = ljpeg_decode(buf[o:o + nbytes], max_samples=tw * th)      # no stream may declare more than its tile holds
         y0, x0 = (k // across) * th, (k % across) * tw
         rows = min(th, h - y0) if not raw.get(TAG_TILE_OFFSETS) else th
         if tile.size < rows * tw:

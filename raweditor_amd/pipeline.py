@@ -77,6 +77,26 @@ class RenderPipeline:
         cp = params.to_c()
         check(_lib.lib().rd_pipeline_create(device, int(image_id), raw.ctypes.data_as(C.c_void_p), int(width),
                                             int(height), C.byref(cp), wb, cm, C.byref(self._h)))
+        return self._finish()
+
+    @classmethod
+    def from_device(cls, image_id: int, cfa_dev: int, width: int, height: int, params: EditParams,
+                    wb_multipliers: Sequence[float], color_matrix: Sequence[float], device: int = 0) -> "RenderPipeline":
+        """The same pipeline over a CFA plane that already lives in `device`'s HBM (rd_pipeline_create_from_device:
+        the plane is copied device-to-device; `cfa_dev` is a device pointer as int)."""
+        if len(wb_multipliers) != 4 or len(color_matrix) != 9:
+            raise RawdevError(-1, "wb_multipliers must have 4 and color_matrix 9 elements")
+        self = object.__new__(cls)
+        self._h = C.c_void_p()
+        self._device = device
+        wb = (C.c_float * 4)(*[float(x) for x in wb_multipliers])
+        cm = (C.c_float * 9)(*[float(x) for x in color_matrix])
+        cp = params.to_c()
+        check(_lib.lib().rd_pipeline_create_from_device(device, int(image_id), C.c_void_p(int(cfa_dev)), int(width),
+                                                        int(height), C.byref(cp), wb, cm, C.byref(self._h)))
+        return self._finish()
+
+    def _finish(self) -> "RenderPipeline":
         info = _lib.RdInfo()
         check(_lib.lib().rd_pipeline_info(self._h, C.byref(info)))
         # the reference's pub fields (pipeline.rs:89-96)

@@ -1,0 +1,107 @@
+"""bench.py's launcher logic, no GPU: `python bench.py --gpus N` (N > 1, no torch.distributed.run around it) must start
+N fresh rank processes with the launcher's environment, relay rank 0's line and fail when a rank fails -- without the
+parent importing torch or touching HIP."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_child_environment():
+    base = {"PATH": "/bin", "RANK": "7", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    envs = [bench.child_env(base, r, 4, 29511) for r in range(4)]
+    for r, e in enumerate(envs):
+        assert e["RANK"] == e["LOCAL_RANK"] == str(r)
+        assert e["WORLD_SIZE"] == e["LOCAL_WORLD_SIZE"] == "4"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29511"
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/bin"
+    assert base["RANK"] == "7"                               # the parent's environment is not modified
+    assert bench.child_env({}, 0, 2, 1)["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"   # set when the shell did not export it
+
+
+def test_argument_defaults_and_modes():
+    a = bench.parse_args([])
+    assert (a.gpus, a.steps, a.warmup, a.frames, a.host, a.static_descriptors) == (1, 20, 3, 256, "ranks", False)
+    a = bench.parse_args(["--gpus", "8", "--host", "node", "--static-descriptors", "--no-extra"])
+    assert (a.gpus, a.host, a.static_descriptors, a.no_extra) == (8, "node", True, True)
+
+
+def test_swapped_halves_is_a_permutation_that_changes_every_descriptor():
+    p = list(range(8))
+    q = bench.swapped_halves(p)
+    assert sorted(q) == p and all(a != b for a, b in zip(p, q))
+    assert bench.swapped_halves([5]) == [5]
+
+
+def _fake_rank_script(tmp_path, fail_rank=None):
+    script = tmp_path / "fake_rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys, time
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        assert "torch" not in sys.modules
+        if r == {fail_rank!r}:
+            sys.exit(3)
+        if {fail_rank!r} is not None and r != {fail_rank!r}:
+            time.sleep(60)                                    # a rank that would wait for the dead one
+        if r == 0:
+            print(json.dumps({{"n_gpus": w, "argv": sys.argv[1:], "local_rank": os.environ["LOCAL_RANK"]}}), flush=True)
+        else:
+            print("rank", r, "says hello")                    # must not reach the parent's stdout
+    """))
+    return str(script)
+
+
+def _run_parent(script, world, extra_env=None):
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"rc = bench.self_launch({world}, ['--gpus', '{world}', '--steps', '2'], script={script!r}); "
+            "assert 'torch' not in sys.modules, 'the launcher parent imported torch'; sys.exit(rc)")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+
+
+def test_self_launch_starts_one_process_per_rank_and_relays_rank0(tmp_path):
+    out = _run_parent(_fake_rank_script(tmp_path), 3)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                       # ONE JSON line on stdout: rank 0's
+    got = json.loads(lines[0])
+    assert got == {"n_gpus": 3, "argv": ["--gpus", "3", "--steps", "2"], "local_rank": "0"}
+    assert "rank 1 says hello" in out.stderr and "rank 2 says hello" in out.stderr
+
+
+def test_self_launch_fails_when_a_rank_fails_and_stops_the_others(tmp_path):
+    import time
+    t0 = time.time()
+    out = _run_parent(_fake_rank_script(tmp_path, fail_rank=1), 2)
+    assert out.returncode == 3, (out.returncode, out.stdout, out.stderr)
+    assert time.time() - t0 < 50.0                           # the surviving rank was stopped, not waited for (it sleeps 60 s)
+
+
+def test_main_routes_a_bare_multi_gpu_call_into_the_launcher(monkeypatch):
+    seen = {}
+    monkeypatch.setattr(bench, "self_launch", lambda world, argv, script=None: seen.update(world=world, argv=list(argv)) or 0)
+    monkeypatch.setattr(bench, "run_ranks", lambda args: seen.update(ranks=True))
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen == {"world": 4, "argv": ["--gpus", "4", "--steps", "3"]}
+    # inside a launcher (RANK / WORLD_SIZE exported) the same command is a rank, not a launcher
+    seen.clear()
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.main()
+    assert seen == {"ranks": True}

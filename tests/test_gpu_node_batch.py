@@ -6,6 +6,10 @@ stream + host thread per entry and the fold are the code a real node runs; and t
 with dlopen, ncclCommInitAll, grouped ncclAllReduce of 768 x u64, in place) runs with a one-rank communicator
 (RD_NODE_REDUCE=rccl).  N > 1 on distinct devices is not measurable here.
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -91,6 +95,31 @@ def test_node_batch_rccl_leg_with_one_rank(gpu_lib, refc, monkeypatch):
     ra = gpu_lib
     monkeypatch.setenv("RD_NODE_REDUCE", "rccl")
     _run_node(ra, refc, [0], 260, 384, 5, ra.FMT_RGBA_F32, seed=3)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STANDIN_SRC = os.path.join(ROOT, "tests", "cpp", "rccl_standin.cpp")
+STANDIN_SO = os.path.join(ROOT, "tests", "cpp", "librccl_standin.so")
+
+
+def build_rccl_standin() -> str:
+    """tests/cpp/rccl_standin.cpp -> tests/cpp/librccl_standin.so (host code over the HIP runtime; hipcc, a few seconds)."""
+    if not os.path.exists(STANDIN_SO) or os.path.getmtime(STANDIN_SO) < os.path.getmtime(STANDIN_SRC):
+        hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
+        subprocess.run([hipcc, "-O1", "-fPIC", "-shared", "-o", STANDIN_SO, STANDIN_SRC], check=True)
+    return STANDIN_SO
+
+
+def test_node_batch_rccl_branch_with_several_ranks_through_the_standin(gpu_lib):
+    """The RCCL branch of rd_node_batch (ncclCommInitAll, the grouped in-place ncclAllReduce loop, 'every device holds the
+    sum') with n = 2 and 4 ranks on ONE GPU, through a host-memory stand-in for librccl (tests/cpp/rccl_standin.cpp).
+    A fresh process: librawdev binds its RCCL library once.  Test infrastructure -- says nothing about RCCL / xGMI."""
+    env = dict(os.environ, RAWDEV_RCCL_LIB=build_rccl_standin())
+    env.pop("RD_NODE_REDUCE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "node_rccl_standin_run.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rccl stand-in ok" in out.stdout
 
 
 def test_node_batch_rejects_bad_arguments(gpu_lib):

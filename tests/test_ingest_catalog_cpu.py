@@ -403,3 +403,108 @@ def test_ljpeg_decoder_under_sanitizers(tmp_path, rng):
     out = subprocess.run([str(exe), str(tmp_path / "corpus.bin")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
     assert "decoded" in out.stdout
+
+
+# ---- round 3: the advisor's findings on the ingest side ---------------------------------------------------------------
+def test_ljpeg_truncated_stream_declaring_a_huge_frame_fails_fast_and_small(rng):
+    """A 100-byte tile must not be able to demand gigabytes: the frame size comes from the decoder's own header walk, is
+    checked against what the TIFF tile can hold BEFORE anything is allocated, and a stream that ends early fails at the
+    row where it ran dry instead of being decoded to the end of the declared frame out of injected zero bits."""
+    import time
+    import tracemalloc
+    from tests.ljpeg_encoder import encode
+    good = bytearray(encode(rng.integers(0, 4096, (8, 16), dtype=np.uint16), precision=12))
+    i = good.find(b"\xff\xc3")
+    huge = bytearray(good)
+    huge[i + 5:i + 9] = struct.pack(">HH", 65535, 32767)          # SOF3 now declares 65535 x 32767 samples (4 GiB of u16)
+    tracemalloc.start()
+    t0 = time.time()
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.ljpeg_decode(bytes(huge), max_samples=16 * 8)      # the tile holds 128 samples
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.ljpeg_decode(bytes(huge))                          # no tile size known: the module's own ceiling
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert time.time() - t0 < 2.0 and peak < (8 << 20), (time.time() - t0, peak)
+    # within the ceiling but far longer than the data: must stop at the first dry row, not after 4096 rows of zeros
+    tall = bytearray(good)
+    tall[i + 5:i + 7] = struct.pack(">H", 4096)
+    t0 = time.time()
+    with pytest.raises(ValueError, match="truncated"):
+        ingest.ljpeg_decode(bytes(tall))
+    assert time.time() - t0 < 1.0
+
+
+def test_ljpeg_frame_header_is_found_by_walking_segments_not_by_searching_bytes(rng):
+    """0xFF 0xC3 inside an APPn / COM payload ahead of the real SOF3 must not size the allocation."""
+    from tests.ljpeg_encoder import encode
+    a = rng.integers(0, 4096, (6, 10), dtype=np.uint16)
+    good = encode(a, precision=12)
+    payload = b"junk\xff\xc3" + b"\x7f" * 12                       # would read as a 32639 x 32639 x 127 frame
+    com = b"\xff\xfe" + struct.pack(">H", 2 + len(payload)) + payload
+    assert np.array_equal(ingest.ljpeg_decode(good[:2] + com + good[2:]), a)
+
+
+def test_ljpeg_restart_interval_must_be_whole_lines(rng):
+    from tests.ljpeg_encoder import encode
+    a = rng.integers(0, 4096, (6, 10), dtype=np.uint16)
+    s = bytearray(encode(a, precision=12, restart_rows=2))
+    i = s.find(b"\xff\xdd")
+    assert i > 0 and struct.unpack_from(">H", s, i + 4)[0] == 20
+    assert np.array_equal(ingest.ljpeg_decode(bytes(s)), a)
+    s[i + 4:i + 6] = struct.pack(">H", 15)                        # 1.5 lines: would be predicted wrongly, silently
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.ljpeg_decode(bytes(s))
+
+
+def test_ljpeg_sizes_are_reported_before_the_capacity_check(rng):
+    import ctypes as C
+    from raweditor_amd import _lib
+    from tests.ljpeg_encoder import encode
+    s = encode(rng.integers(0, 4096, (5, 8), dtype=np.uint16), components=2, precision=12)
+    dims = [C.c_uint32(99) for _ in range(4)]
+    src = (C.c_uint8 * len(s)).from_buffer_copy(s)
+    rc = _lib.lib().rd_ljpeg_decode(src, len(s), None, 0, *[C.byref(d) for d in dims])
+    assert rc != 0 and [d.value for d in dims] == [4, 5, 2, 12]
+    rc = _lib.lib().rd_ljpeg_decode(src, 20, None, 0, *[C.byref(d) for d in dims])      # fails before the frame is known
+    assert rc != 0 and [d.value for d in dims] == [0, 0, 0, 0]
+
+
+def test_unpack_bits_is_chunked_and_exact_at_scale(rng, monkeypatch):
+    """10 / 12 / 14-bit unpacking by whole-byte groups, a bounded block of rows at a time: exact against the bit-by-bit
+    definition, also when a row is shorter than its last group and when the block size forces many passes."""
+    monkeypatch.setattr(ingest, "_UNPACK_CHUNK_BYTES", 64)        # several passes even for tiny inputs
+    for bits in (10, 12, 14):
+        for w in (1, 2, 3, 4, 5, 13, 64):
+            cfa = rng.integers(0, 1 << bits, (9, w), dtype=np.uint16)
+            assert np.array_equal(ingest.unpack_bits(_pack_rows(cfa, bits), w, bits), cfa), (bits, w)
+    monkeypatch.undo()
+    import tracemalloc
+    cfa = rng.integers(0, 4096, (512, 2048), dtype=np.uint16)     # 1 MP
+    packed = _pack_rows(cfa, 12)
+    tracemalloc.start()
+    got = ingest.unpack_bits(packed, 2048, 12)
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert np.array_equal(got, cfa)
+    assert peak < 16 * cfa.size, peak                             # round 2's form needed ~100 bytes per sample
+
+
+def test_dng_subifd_offsets_of_tiff_type_13(tmp_path, rng):
+    """Tag 330 written with TIFF type 13 (IFD) instead of LONG -- what many writers do -- must be followed."""
+    cfa = rng.integers(0, 4096, (6, 8), dtype=np.uint16)
+    path = tmp_path / "t13.dng"
+    _write_dng(path, cfa, "<", strips=1)
+    buf = bytearray(path.read_bytes())
+    (n,) = struct.unpack_from("<H", buf, 8)
+    hit = False
+    for k in range(n):
+        tag, typ = struct.unpack_from("<HH", buf, 10 + 12 * k)
+        if tag == 330:
+            assert typ == 4
+            struct.pack_into("<H", buf, 10 + 12 * k + 2, 13)
+            hit = True
+    assert hit
+    path.write_bytes(bytes(buf))
+    r = ingest.load_dng(str(path))
+    assert np.array_equal(r.data.reshape(6, 8), cfa)
