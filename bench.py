@@ -439,14 +439,14 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream):
     out = {}
     t0 = time.perf_counter()
     out["single_frame_f32"] = extra_single_frame(torch, np, ra, dev, dev_index, cfas[0], params[0], stream)
-    n8 = min(64, len(cfas))
-    out["batch_rgba8"] = extra_batch(torch, np, ra, dev, dev_index, "u8", cfas[:n8], params[:n8], 6016, 4016, 32, 1, 5, stream,
+    n8 = len(cfas)
+    out["batch_rgba8"] = extra_batch(torch, np, ra, dev, dev_index, "u8", cfas[:n8], params[:n8], 6016, 4016, 32, 1, 6, stream,
                                      f"the reference's own surface (Rgba8Unorm, pipeline.rs:322) on the batch workload: {n8} x 6016x4016, "
                                      "randomised stacks, fused histogram, strict f32 arithmetic", "multi")
     W5, H5 = 11648, 8736
-    c5, p5 = make_batch(torch, np, ra, dev, W5, H5, 8, 1 << 20, 1)
-    out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3, stream,
-                                           "BASELINE configs[4] shape on one GPU: 8 x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
+    c5, p5 = make_batch(torch, np, ra, dev, W5, H5, 16, 1 << 20, 1)
+    out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 6, stream,
+                                           "BASELINE configs[4] shape on one GPU: 16 x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
                                            "row_bands 8, randomised stacks, fused histogram, strict f32 arithmetic", "multi")
     del c5
     out["seconds"] = round(time.perf_counter() - t0, 1)

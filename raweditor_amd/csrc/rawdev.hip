@@ -1386,11 +1386,13 @@ __global__ void __launch_bounds__(256) rd_q8_sweep(uint32_t base, rd_q8_stats *s
     if (codes) codes[i] = (uint8_t)fast;
     if (!st) return;
     if (fast != exact || fast > 255u) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
-    if (x >= RD_FLT_MIN) {
-        float y = __builtin_fmaf(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * RD_INV_GAMMA), 255.0f, 0.5f);
-        y = __builtin_fminf(y, 255.5f);
-        const float d = __builtin_fabsf(y - (rd_gamma_clamp(x) * 255.0f + 0.5f));
-        if (__builtin_fabsf(__builtin_amdgcn_fractf(y) - 0.5f) > 0.5f - RD_Q8_EPS) atomicAdd(&st->fallbacks, 1ull);
+    if (x >= RD_FLT_MIN) {                                       // diagnostics: how often the pinned evaluation decides, and how far
+        float z;                                                 // the hardware 255 e is from the pinned 255 g (in codes)
+        const float e = rd_hw_gamma01(x, z);
+        const float t = __builtin_fmaf(e, 255.0f, RD_MAGIC23);
+        const float dn = __builtin_fmaf(e, 255.0f, -(t - RD_MAGIC23));
+        if (__builtin_fabsf(dn) > 0.5f - RD_Q8_EPS) atomicAdd(&st->fallbacks, 1ull);
+        const float d = __builtin_fabsf(e * 255.0f - rd_gamma_clamp(x) * 255.0f);
         atomicMax(&st->max_dist_bits, rd_f2u(d));               // d >= 0: integer order == float order
     }
 }

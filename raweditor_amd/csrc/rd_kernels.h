@@ -41,6 +41,19 @@ typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
 
 struct rd_rgb { float r, g, b; };
 
+// The elision flags of a frame (rd_uniforms.h).  tools/isa_budget.py compiles the kernels with -DRD_BUDGET_ELIDE=<flags> to
+// pin them at compile time: the assembly then holds exactly ONE path through the colour stack (the one a frame with those
+// flags takes), so its static instruction count is that frame's dynamic count.  Never defined in the product build.
+__device__ __forceinline__ uint32_t rd_elide_of(const rd_ku &u)
+{
+#ifdef RD_BUDGET_ELIDE
+    (void)u;
+    return RD_BUDGET_ELIDE;
+#else
+    return u.elide;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // The colour stack (shaders.rs:192-266): rd_colour_n below; rd_dot709 is its Rec.709 luma (:222, :243, :256).
 // ---------------------------------------------------------------------------------------------
@@ -68,7 +81,7 @@ __device__ __forceinline__ void rd_levels_divide(const rd_ku &u, float (&v)[M])
     if (MATH == RD_MATH_CONTRACTED) {
 #pragma unroll
         for (int k = 0; k < M; ++k) v[k] = v[k] * u.rden;
-    } else if (u.elide & RD_EL_FIX) {                            // one residual correction (proof: above)
+    } else if (rd_elide_of(u) & RD_EL_FIX) {                     // one residual correction (proof: above)
 #pragma unroll
         for (int k = 0; k < M; ++k) {
             const float t = v[k] * u.rden;
@@ -109,7 +122,7 @@ template <int N, int MATH, bool GAMMA = true>
 __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
 {
     constexpr bool C = MATH == RD_MATH_CONTRACTED;
-    const uint32_t el = u.elide;
+    const uint32_t el = rd_elide_of(u);
 #pragma unroll
     for (int i = 0; i < N; ++i) { r[i] = r[i] * u.wb_r; g[i] = g[i] * u.wb_g; b[i] = b[i] * u.wb_b; }          // :195
     if (!(el & RD_EL_K)) {
@@ -220,7 +233,7 @@ template <int MATH>
 __device__ __forceinline__ void rd_colour_separable(const rd_ku &u, float (&v)[5])
 {
     constexpr bool C = MATH == RD_MATH_CONTRACTED;
-    const uint32_t el = u.elide;
+    const uint32_t el = rd_elide_of(u);
     v[0] = v[0] * u.wb_r; v[1] = v[1] * u.wb_g; v[2] = v[2] * u.wb_g; v[3] = v[3] * u.wb_b; v[4] = v[4] * u.wb_b;       // :195
     if (!(el & RD_EL_K)) {                                                                                         // :200-205
         v[0] = v[0] * u.kr; v[3] = v[3] * u.kb; v[4] = v[4] * u.kb; v[1] = v[1] * u.kg; v[2] = v[2] * u.kg;
@@ -254,6 +267,11 @@ __device__ __forceinline__ float rd_norm(uint32_t raw, uint32_t bl)
     return (float)raw * (1.0f / 4096.0f);
 }
 
+// The same for black level 0 (the reference has none) without a conversion: 0x45000000 is 2^11, whose ulp is
+// 2^-12, so the encoding 0x45000000 | raw IS the float 2^11 + raw * 2^-12 (raw < 2^23), and subtracting 2^11 leaves
+// raw / 4096 exactly -- one or + one full-rate subtract instead of v_cvt_f32_u32 (half rate) + multiply.
+__device__ __forceinline__ float rd_norm0(uint32_t raw16) { return rd_u2f(raw16 | 0x45000000u) - 2048.0f; }
+
 // Rgba8Unorm quantisation (pipeline.rs:322), pinned as trunc(RN(x*255) + 0.5).  x is always a clamped gamma value in
 // [0, 1], and for every float in [0, 1] one fma gives the same integer as the multiply-then-add
 // (tools/q8_fma_check.c: all 1 065 353 217 encodings; tests/test_host_cpu.py runs it), so the code costs one
@@ -264,25 +282,62 @@ __device__ __forceinline__ uint32_t rd_q8(float x) { return (uint32_t)__builtin_
 // pipeline.rs:322 -- and RGB8), in a third of the instructions.  The code is a step function of x with 255 steps; between
 // two steps ANY evaluation of pow(x, 1/2.2) that is accurate to a small fraction of a code gives the same answer.  So:
 // the hardware's v_log_f32 / v_exp_f32 (about 1 ULP each; the lowering the reference's Vulkan drivers use, rd_math.h)
-// give y' = 255 * 2^(log2(x) / 2.2) + 0.5, whose distance from the pinned y is below RD_Q8_EPS codes for every float
-// (tools/q8_exhaustive.hip measures the largest distance over all 2^32 encodings), and only a lane whose y' lies within
-// RD_Q8_EPS of an integer -- where the two could fall on different sides of a step -- takes the pinned evaluation
-// (about one lane in 2000; the branch is skipped when no lane of the wave needs it).  Measured largest distance:
-// 3.05e-5 codes (profiles/r02_q8_exhaustive.txt); RD_Q8_EPS keeps 8x that.  Every float encoding is checked
-// against rd_q8(rd_gamma_clamp(x)) on the device and against the oracle's pow + clamp + pack on the host by
-// tools/q8_exhaustive.hip (tests/test_gpu_q8.py runs the device half in the -m gpu suite).
+// give e = 2^(log2(x) / 2.2), whose 255 e lies within 3.05e-5 codes of the pinned 255 g for every float
+// (tools/q8_exhaustive.hip measures the largest distance over all 2^32 encodings, profiles/r02_q8_exhaustive.txt), and
+// only a lane whose 255 e lies within RD_Q8_EPS (8x that) of a half-integer -- where the two could round to different
+// codes -- takes the pinned evaluation (about one lane in 2000; the branch is skipped when no lane of the wave needs it).
+//
+// Round 3: the same decision in instructions that issue at the full rate (tools/isa_budget.py prices them; the round-2
+// form spent 46 issue cycles per value, this one 28 -- profiles/r03_isa_budget_*.txt):
+//   * e is clamped to [0, 1] by the OUTPUT MODIFIER of v_exp_f32 (no v_min; with the HSA default DX10_CLAMP a NaN -- a
+//     negative x -- becomes 0, so every x below FLT_MIN, zero, negative or NaN gives e = 0 and code 0 without a compare
+//     and select of its own);
+//   * the code is taken by the add-magic idiom: t = RN(255 e + 2^23) is ONE fma and carries round-to-nearest(255 e) in the
+//     low byte of its encoding (0x4b0000qq) -- no v_cvt_u32_f32, no v_fract; nearest-even instead of the pin's
+//     trunc(. + 0.5) differs only on exact ties, which lie inside the zone the pinned evaluation decides;
+//   * the distance to the nearest half-integer is d = fma(e, 255, -(t - 2^23)) (exact difference, rounded once).
+// Every float encoding is checked against rd_q8(rd_gamma_clamp(x)) on the device (rd_selftest_q8, tests/test_gpu_q8.py
+// in the -m gpu suite) and against the oracle's pow + clamp + pack on the host by tools/q8_exhaustive.hip.
 #ifndef RD_Q8_EPS
 #define RD_Q8_EPS 0.00025f
 #endif
+#define RD_MAGIC23 8388608.0f               /* 2^23 = 0x4b000000: RN(v + 2^23) carries RN(v) in its low mantissa bits */
+#define RD_MAGIC23_BITS 0x4b000000u
+
+// Lane constants of the shortcuts.  A VOP3 instruction takes no literal on gfx9 and an SGPR source halves the issue rate of
+// v_fma_f32 (tools/valu_probe2.hip), so the export kernel parks these in VGPRs once per wave (rd_kc_parked); the map
+// kernel and the self-tests let the compiler place them.
+struct rd_kc {
+    float k255;                                                  // 255.0
+    float f16_ka, f16_kb;                                        // RD_F16_KA / 64, RD_F16_KB / 64 (rd_f16_gamma)
+};
+
+// e = clamp(2^(log2(x) / 2.2), 0, 1) on the hardware pair; z = log2(x) / 2.2.  fmed3(., 0, 1) is the clamp idiom hipcc
+// folds into the producing instruction's output modifier (v_exp_f32_e64 ... clamp).
+__device__ __forceinline__ float rd_hw_gamma01(float x, float &z)
+{
+    z = __builtin_amdgcn_logf(x) * RD_INV_GAMMA;
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(z), 0.0f, 1.0f);
+}
+
+// The 8-bit code of x as the ENCODING 0x4b0000qq (qq = the code): the histogram address and the pixel pack take their
+// byte from it without a conversion.
+__device__ __forceinline__ uint32_t rd_q8_gamma_bits(float x, const rd_kc &kc)
+{
+    float z;
+    const float e = rd_hw_gamma01(x, z);
+    const float t = __builtin_fmaf(e, kc.k255, RD_MAGIC23);      // RN(255 e + 2^23): in [2^23, 2^23 + 255]
+    const float r = t - RD_MAGIC23;                              // the rounded code as a float (exact)
+    const float d = __builtin_fmaf(e, kc.k255, -r);              // 255 e - code, |d| <= 0.5
+    uint32_t tb = rd_f2u(t);
+    if (__builtin_fabsf(d) > 0.5f - RD_Q8_EPS) tb = RD_MAGIC23_BITS | rd_q8(rd_gamma_clamp(x));
+    return tb;
+}
+
 __device__ __forceinline__ uint32_t rd_q8_gamma(float x)
 {
-    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * RD_INV_GAMMA);
-    float y = __builtin_fmaf(e, 255.0f, 0.5f);
-    y = __builtin_fminf(y, 255.5f);                              // x >= 1 and +inf: code 255
-    uint32_t q = (uint32_t)y;
-    const float f = __builtin_amdgcn_fractf(y) - 0.5f;
-    if (__builtin_fabsf(f) > 0.5f - RD_Q8_EPS) q = rd_q8(rd_gamma_clamp(x));
-    return x >= RD_FLT_MIN ? q : 0u;                             // negative, NaN, zero, subnormal: code 0 (rd_gamma_clamp's cases)
+    const rd_kc kc = { 255.0f, 0.0f, 0.0f };
+    return rd_q8_gamma_bits(x, kc) & 0xffu;
 }
 
 // The same shortcut for the RGBA-f16 surface (BASELINE config 5): what leaves the kernel is the binary16 rounding of the
@@ -291,33 +346,59 @@ __device__ __forceinline__ uint32_t rd_q8_gamma(float x)
 // (tools/f16_err_probe.hip: largest relative distance 1.41 * 2^-23 for |z| < 1, 3.9 below 7, 12.1 below 29, 23.2 beyond;
 // the bound keeps 1.5x that) -- i.e. within K = 2.4 |z| + 4.5 of its own f32 ulps.  binary16 keeps 10 of the 23 fraction
 // bits and rounds to nearest, so the pinned value and e round to the same half unless the 13 discarded bits of e lie
-// within K of the midpoint 0x1000; only then (about one lane in 800 for bright pixels), and below binary16's normal
-// range, the pinned evaluation decides.  Checked for all 2^32 encodings against binary16(rd_gamma_clamp(x)) by
-// rd_selftest_f16 / tests/test_gpu_q8.py.
+// within K of the midpoint 0x1000; only then (about one lane in 800 for bright pixels), and in binary16's subnormal
+// range, the pinned evaluation decides.  The function returns a FLOAT whose binary16 rounding is the pinned half (e, or
+// the pinned g for the deciding lanes), so the caller converts pairs with one v_cvt_pk_f16_f32.
+// Round 3, same decisions at the full issue rate (68 -> 48 cycles per value): the clamp is v_exp_f32's output modifier
+// (e = 0 for every x below FLT_MIN, zero, negative or NaN: half 0 and code 0 with no compare of their own); the 13 low
+// bits are compared as (bits - 4096) / 64 against K / 64, K / 64 = clamp(|z| * KA/64 + KB/64) by the fma's output
+// modifier, so an infinite z (x = 0) no longer sends a wave of black pixels through the pinned evaluation (K > 64 only
+// where binary16 is subnormal anyway); "0 < e < 2^-14" is one integer compare on bits(e) - 1.
+// Checked for all 2^32 encodings against binary16(rd_gamma_clamp(x)) by rd_selftest_f16 / tests/test_gpu_q8.py.
 #define RD_F16_KA 2.4f
 #define RD_F16_KB 4.5f
 template <bool WANT_Q>
-__device__ __forceinline__ void rd_f16_gamma(float x, uint32_t &h, uint32_t &q)
+__device__ __forceinline__ float rd_f16_gamma_value(float x, const rd_kc &kc, uint32_t &tb)
 {
-    const float z = __builtin_amdgcn_logf(x) * RD_INV_GAMMA;
-    const float e = __builtin_fminf(__builtin_amdgcn_exp2f(z), 1.0f);        // x >= 1 and +inf: 1.0
-    // the 13 discarded fraction bits as a float (0 ... 8191, exact): 2^23 + bits is representable, minus 2^23
-    const float lowbits = rd_u2f((rd_f2u(e) & 0x1fffu) | 0x4b000000u) - 8388608.0f;
-    const float k = __builtin_fmaf(__builtin_fabsf(z), RD_F16_KA, RD_F16_KB);
-    bool near = __builtin_fabsf(lowbits - 4096.0f) <= k || e < 6.103515625e-05f;   // near a rounding midpoint, or subnormal half
-    h = __builtin_bit_cast(uint16_t, (_Float16)e);
-    q = 0u;
+    float z;
+    float e = rd_hw_gamma01(x, z);
+    const uint32_t eb = rd_f2u(e);
+    // (the 13 discarded fraction bits - 4096) / 64, exact: 2^17 + bits * 2^-6 is representable, minus (2^17 + 64)
+    const float lowm = rd_u2f((eb & 0x1fffu) | 0x48000000u) - 131136.0f;
+    const float k = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_fabsf(z), kc.f16_ka, kc.f16_kb), 0.0f, 1.0f);
+    bool near = __builtin_fabsf(lowm) <= k;                      // within K of a rounding midpoint
+    near = near || (eb - 1u) < 0x387fffffu;                     // 0 < e < 2^-14: a subnormal half
+    tb = 0u;
     if (WANT_Q) {
-        const float y = __builtin_fmaf(e, 255.0f, 0.5f);                     // <= 255.5
-        q = (uint32_t)y;
-        near = near || __builtin_fabsf(__builtin_amdgcn_fractf(y) - 0.5f) > 0.5f - RD_Q8_EPS;
+        const float t = __builtin_fmaf(e, kc.k255, RD_MAGIC23);
+        const float r = t - RD_MAGIC23;
+        const float d = __builtin_fmaf(e, kc.k255, -r);
+        tb = rd_f2u(t);
+        near = near || __builtin_fabsf(d) > 0.5f - RD_Q8_EPS;
     }
     if (near) {
-        const float g = rd_gamma_clamp(x);
-        h = __builtin_bit_cast(uint16_t, (_Float16)g);
-        if (WANT_Q) q = rd_q8(g);
+        e = rd_gamma_clamp(x);
+        if (WANT_Q) tb = RD_MAGIC23_BITS | rd_q8(e);
     }
-    if (!(x >= RD_FLT_MIN)) { h = 0u; q = 0u; }                  // negative, NaN, zero, subnormal: rd_gamma_clamp gives +0
+    return e;
+}
+
+// binary16 pair (lo, hi) of two such values: one v_cvt_pk_f16_f32 (gfx950; round to nearest even)
+__device__ __forceinline__ uint32_t rd_pack_h2(float lo, float hi)
+{
+    typedef float rd_f2v __attribute__((ext_vector_type(2)));
+    const rd_f2v v = { lo, hi };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rd_h2));
+}
+
+template <bool WANT_Q>
+__device__ __forceinline__ void rd_f16_gamma(float x, uint32_t &h, uint32_t &q)      // self-tests: half and code of one value
+{
+    const rd_kc kc = { 255.0f, RD_F16_KA / 64.0f, RD_F16_KB / 64.0f };
+    uint32_t tb;
+    const float e = rd_f16_gamma_value<WANT_Q>(x, kc, tb);
+    h = __builtin_bit_cast(uint16_t, (_Float16)e);
+    q = tb & 0xffu;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,6 +422,31 @@ __device__ __forceinline__ void rd_hist_add(uint32_t *lh, uint32_t copy, uint32_
     atomicAdd(&lh[(qr)*RD_HK + copy], inc);
     atomicAdd(&lh[(256u + qg) * RD_HK + copy], inc);
     atomicAdd(&lh[(512u + qb) * RD_HK + copy], inc);
+}
+
+// The same three adds for codes that arrive as add-magic encodings 0x4b0000qq (rd_q8_gamma_bits): the byte address of
+// bin q, copy c is q * 4 RD_HK + 4 c, and (bits << s) + base with base = 4 c - (0x4b000000 << s) (mod 2^32) is exactly that
+// -- one v_lshl_add_u32 per bin, no extraction of the code; the channel offset rides in the ds instruction's offset field.
+// `hbase` = rd_hist_base(copy), once per wave.
+#define RD_HIST_SHIFT (2 + (RD_HK == 8 ? 3 : RD_HK == 4 ? 2 : RD_HK == 16 ? 4 : RD_HK == 32 ? 5 : 0))
+static_assert(RD_HK == 4 || RD_HK == 8 || RD_HK == 16 || RD_HK == 32, "RD_HK must be 4, 8, 16 or 32");
+__device__ __forceinline__ uint32_t rd_hist_base(uint32_t copy) { return copy * 4u - (RD_MAGIC23_BITS << RD_HIST_SHIFT); }
+
+__device__ __forceinline__ void rd_hist_add_bits(uint32_t *lh, uint32_t hbase, uint32_t tr, uint32_t tg, uint32_t tb, uint32_t inc)
+{
+    char *base = reinterpret_cast<char *>(lh);
+    atomicAdd(reinterpret_cast<uint32_t *>(base + ((tr << RD_HIST_SHIFT) + hbase)), inc);
+    atomicAdd(reinterpret_cast<uint32_t *>(base + ((tg << RD_HIST_SHIFT) + hbase)) + 256u * RD_HK, inc);
+    atomicAdd(reinterpret_cast<uint32_t *>(base + ((tb << RD_HIST_SHIFT) + hbase)) + 512u * RD_HK, inc);
+}
+
+// RGBA8 / RGB8 pixel from three such encodings: two byte permutes (v_perm_b32: selector bytes 0-3 pick the second operand's
+// bytes, 4-7 the first operand's, 0x0c gives 0x00 and 0xff gives 0xff) instead of shift-or, shift-or, or.
+template <bool ALPHA>
+__device__ __forceinline__ uint32_t rd_pack_rgba_bits(uint32_t tr, uint32_t tg, uint32_t tb)
+{
+    const uint32_t rg = __builtin_amdgcn_perm(tg, tr, 0x0c0c0400u);              // [r, g, 0, 0]
+    return __builtin_amdgcn_perm(tb, rg, ALPHA ? 0xff040100u : 0x0c040100u);     // [r, g, b, 0xff / 0]
 }
 
 __device__ __forceinline__ void rd_hist_flush(const uint32_t *lh, uint32_t *slab32,
@@ -499,11 +605,18 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         RD_PARK(wb_r); RD_PARK(wb_g); RD_PARK(wb_b); RD_PARK(kr); RD_PARK(kg); RD_PARK(kb);
         RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
         RD_PARK(den); RD_PARK(rden);                             // 36 uses per tile in the divide's FMA chains
-        if constexpr (FMT != RD_FMT_RGBA_F32) {                  // the narrower surfaces carry fewer live VGPRs: park six more
+        if constexpr (FMT != RD_FMT_RGBA_F32) {                  // the narrower surfaces carry fewer live VGPRs: park six to eight more
             RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
+            if constexpr (FMT != RD_FMT_RGB_U8) { RD_PARK(highlights); RD_PARK(shadows); }     // (RGB8's LDS repack needs the registers)
         }
 #undef RD_PARK
     };
+    // lane constants of the gamma shortcuts (rd_kc), in VGPRs for the same reason; the asm keeps them there
+    rd_kc kc = { 255.0f, RD_F16_KA / 64.0f, RD_F16_KB / 64.0f };
+    if constexpr (FMT != RD_FMT_RGBA_F32) {
+        asm volatile("" : "+v"(kc.k255));
+        if constexpr (FMT == RD_FMT_RGBA_F16) asm volatile("" : "+v"(kc.f16_ka), "+v"(kc.f16_kb));
+    }
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
@@ -588,20 +701,38 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 
     // cfa[ra][2q..2q+1] and cfa[rb][2q..2q+1] of tile (pu, pq) for this lane; rows clamped to the image.
     auto load_tile = [&](uint32_t pu, uint32_t pq, uint32_t &top, uint32_t &bot) {
-        uint32_t q = pq * 64u + lane;
-        if (!FULL) q = q < qpr ? q : qpr - 1u;                   // clamp: loaded but never used
         const uint32_t ra = pu ? 2u * pu - 1u : 0u;
         const uint32_t rb = 2u * pu < H ? 2u * pu : H - 1u;
-        top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W)[q];
-        bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)rb * W)[q];
+        if constexpr (FULL) {
+            // wave-uniform base (SALU, 64-bit) + the lane's own dword: global_load_dword v_lane4, s[base] -- no per-tile
+            // 64-bit VALU address arithmetic (it was 14 issue cycles per tile, tools/isa_budget.py)
+            top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)ra * W + (size_t)pq * 128u))[lane];
+            bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)rb * W + (size_t)pq * 128u))[lane];
+        } else {
+            uint32_t q = pq * 64u + lane;
+            q = q < qpr ? q : qpr - 1u;                          // clamp: loaded but never used
+            top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W)[q];
+            bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)rb * W)[q];
+        }
     };
 
     // demosaic + colour stack + histogram of one tile -> packed results
     auto compute_tile = [&](uint32_t tu, uint32_t tq, uint32_t top, uint32_t bot) {
         const bool has_a = tu != 0u, has_b = 2u * tu < H;        // wave-uniform
         const bool valid = FULL || (tq * 64u + lane) < qpr;
-        const float A = rd_norm(top & 0xffffu, u.black_level), B = rd_norm(top >> 16, u.black_level);
-        const float C = rd_norm(bot & 0xffffu, u.black_level), D = rd_norm(bot >> 16, u.black_level);
+        float A, B, C, D;
+#ifdef RD_BUDGET_ELIDE                                           // tools/isa_budget.py: one path in the assembly
+        constexpr bool black0 = true;
+#else
+        const bool black0 = u.black_level == 0u;
+#endif
+        if (black0) {                                            // wave-uniform; the reference's case
+            A = rd_norm0(top & 0xffffu); B = rd_norm0(top >> 16);
+            C = rd_norm0(bot & 0xffffu); D = rd_norm0(bot >> 16);
+        } else {
+            A = rd_norm(top & 0xffffu, u.black_level); B = rd_norm(top >> 16, u.black_level);
+            C = rd_norm(bot & 0xffffu, u.black_level); D = rd_norm(bot >> 16, u.black_level);
+        }
 #if defined(RD_COLOUR_HOOK_HEADER) || defined(RD_NO_Q8_SHORTCUT)   // microbench stand-ins / A/B builds (tools/): the narrow
         constexpr bool Q8ONLY = false, H16 = false;                    // surfaces go through the pinned gamma like the f32 one
 #else
@@ -613,37 +744,45 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 #else
         constexpr bool F32T = FMT == RD_FMT_RGBA_F32;      // f32 surface: gamma, histogram and stage write triple by triple (below)
 #endif
+        // 8-bit codes of the three triples.  BITS (the narrow surfaces' shortcut paths): as add-magic ENCODINGS 0x4b0000qq
+        // (rd_q8_gamma_bits) -- the histogram address and the pixel pack take the byte straight from them; otherwise plain codes.
+        constexpr bool BITS = Q8ONLY || H16;
         uint32_t q1r = 0, q1g = 0, q1b = 0, q2r = 0, q2g = 0, q2b = 0, q3r = 0, q3g = 0, q3b = 0;
         uint32_t ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0, hc0 = 0, hc1 = 0;       // binary16 pairs (r, g), (b, 1.0) of c1, c2, c3 (H16)
         rd_rgb c1 = { 0.0f, 0.0f, 0.0f }, c2 = c1, c3 = c1;
+        const uint32_t hbase = rd_hist_base(copy);               // loop-invariant: hoisted
+        auto count = [&](uint32_t qr, uint32_t qg, uint32_t qb, uint32_t inc) {      // one pixel's codes into the histogram
+            if constexpr (BITS) rd_hist_add_bits(lh, hbase, qr, qg, qb, inc);
+            else rd_hist_add(lh, copy, qr, qg, qb, inc);
+        };
         bool separable = false;                                  // wave-uniform
 #ifndef RD_COLOUR_HOOK_HEADER
         // (not for the f32 surface: it sits on its memory floor with or without the shortcut -- 76.5 us per frame either way --
         // and the extra path costs its general case 0.3 %)
-        if constexpr (Q8ONLY || H16) separable = (u.elide & RD_EL_SEPARABLE) == RD_EL_SEPARABLE;
+        if constexpr (Q8ONLY || H16) separable = (rd_elide_of(u) & RD_EL_SEPARABLE) == RD_EL_SEPARABLE;
         if (separable) {
             // No step of THIS frame's stack mixes channels (the usual edit): five distinct values instead of nine
             // (rd_colour_separable); triple 1 = (v0, v1, v3), triple 2 = (v0, v2, v4), triple 3 = (v0, v2, v3).
             float v[5] = { C, A, D, B, A };
             rd_colour_separable<MATH>(u, v);
             if constexpr (Q8ONLY) {
-                q1r = rd_q8_gamma(v[0]); q1g = rd_q8_gamma(v[1]); q1b = rd_q8_gamma(v[3]);
-                q2g = rd_q8_gamma(v[2]); q2b = rd_q8_gamma(v[4]);
+                q1r = rd_q8_gamma_bits(v[0], kc); q1g = rd_q8_gamma_bits(v[1], kc); q1b = rd_q8_gamma_bits(v[3], kc);
+                q2g = rd_q8_gamma_bits(v[2], kc); q2b = rd_q8_gamma_bits(v[4], kc);
                 q2r = q1r; q3r = q1r; q3g = q2g; q3b = q1b;
                 if (HIST && valid) {
-                    if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
-                    if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
+                    if (has_a) count(q1r, q1g, q1b, 2u);
+                    if (has_b) { count(q2r, q2g, q2b, 1u); count(q3r, q3g, q3b, 1u); }
                 }
             } else if constexpr (H16) {
-                uint32_t hr, hg, hb, hg2, hb2;
-                rd_f16_gamma<HIST>(v[0], hr, q1r); rd_f16_gamma<HIST>(v[1], hg, q1g); rd_f16_gamma<HIST>(v[3], hb, q1b);
-                ha0 = hr | (hg << 16); ha1 = hb | 0x3c000000u;
-                if (HIST && valid && has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
-                rd_f16_gamma<HIST>(v[2], hg2, q2g); rd_f16_gamma<HIST>(v[4], hb2, q2b);
+                const float er = rd_f16_gamma_value<HIST>(v[0], kc, q1r), eg = rd_f16_gamma_value<HIST>(v[1], kc, q1g);
+                const float eb = rd_f16_gamma_value<HIST>(v[3], kc, q1b);
+                ha0 = rd_pack_h2(er, eg); ha1 = rd_pack_h2(eb, 1.0f);
+                if (HIST && valid && has_a) count(q1r, q1g, q1b, 2u);
+                const float eg2 = rd_f16_gamma_value<HIST>(v[2], kc, q2g), eb2 = rd_f16_gamma_value<HIST>(v[4], kc, q2b);
                 q2r = q1r; q3r = q1r; q3g = q2g; q3b = q1b;
-                hb0 = hr | (hg2 << 16); hb1 = hb2 | 0x3c000000u;
+                hb0 = rd_pack_h2(er, eg2); hb1 = rd_pack_h2(eb2, 1.0f);
                 hc0 = hb0; hc1 = ha1;
-                if (HIST && valid && has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
+                if (HIST && valid && has_b) { count(q2r, q2g, q2b, 1u); count(q3r, q3g, q3b, 1u); }
             }
         }
 #endif
@@ -658,20 +797,20 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         c1 = rd_rgb{ tr[0], tg[0], tb[0] }; c2 = rd_rgb{ tr[1], tg[1], tb[1] }; c3 = rd_rgb{ tr[2], tg[2], tb[2] };
 #endif
         if constexpr (Q8ONLY) {
-            q1r = rd_q8_gamma(c1.r); q1g = rd_q8_gamma(c1.g); q1b = rd_q8_gamma(c1.b);
-            q2r = rd_q8_gamma(c2.r); q2g = rd_q8_gamma(c2.g); q2b = rd_q8_gamma(c2.b);
-            q3r = rd_q8_gamma(c3.r); q3g = rd_q8_gamma(c3.g); q3b = rd_q8_gamma(c3.b);
+            q1r = rd_q8_gamma_bits(c1.r, kc); q1g = rd_q8_gamma_bits(c1.g, kc); q1b = rd_q8_gamma_bits(c1.b, kc);
+            q2r = rd_q8_gamma_bits(c2.r, kc); q2g = rd_q8_gamma_bits(c2.g, kc); q2b = rd_q8_gamma_bits(c2.b, kc);
+            q3r = rd_q8_gamma_bits(c3.r, kc); q3g = rd_q8_gamma_bits(c3.g, kc); q3b = rd_q8_gamma_bits(c3.b, kc);
         } else if constexpr (H16) {                               // triple by triple: halves packed and codes counted at once,
-            uint32_t hr, hg, hb;                                  // so that at most one triple's values are live
-            rd_f16_gamma<HIST>(c1.r, hr, q1r); rd_f16_gamma<HIST>(c1.g, hg, q1g); rd_f16_gamma<HIST>(c1.b, hb, q1b);
-            ha0 = hr | (hg << 16); ha1 = hb | 0x3c000000u;
-            if (HIST && valid && has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
-            rd_f16_gamma<HIST>(c2.r, hr, q2r); rd_f16_gamma<HIST>(c2.g, hg, q2g); rd_f16_gamma<HIST>(c2.b, hb, q2b);
-            hb0 = hr | (hg << 16); hb1 = hb | 0x3c000000u;
-            if (HIST && valid && has_b) rd_hist_add(lh, copy, q2r, q2g, q2b, 1u);
-            rd_f16_gamma<HIST>(c3.r, hr, q3r); rd_f16_gamma<HIST>(c3.g, hg, q3g); rd_f16_gamma<HIST>(c3.b, hb, q3b);
-            hc0 = hr | (hg << 16); hc1 = hb | 0x3c000000u;
-            if (HIST && valid && has_b) rd_hist_add(lh, copy, q3r, q3g, q3b, 1u);
+            float er, eg, eb;                                     // so that at most one triple's values are live
+            er = rd_f16_gamma_value<HIST>(c1.r, kc, q1r); eg = rd_f16_gamma_value<HIST>(c1.g, kc, q1g); eb = rd_f16_gamma_value<HIST>(c1.b, kc, q1b);
+            ha0 = rd_pack_h2(er, eg); ha1 = rd_pack_h2(eb, 1.0f);
+            if (HIST && valid && has_a) count(q1r, q1g, q1b, 2u);
+            er = rd_f16_gamma_value<HIST>(c2.r, kc, q2r); eg = rd_f16_gamma_value<HIST>(c2.g, kc, q2g); eb = rd_f16_gamma_value<HIST>(c2.b, kc, q2b);
+            hb0 = rd_pack_h2(er, eg); hb1 = rd_pack_h2(eb, 1.0f);
+            if (HIST && valid && has_b) count(q2r, q2g, q2b, 1u);
+            er = rd_f16_gamma_value<HIST>(c3.r, kc, q3r); eg = rd_f16_gamma_value<HIST>(c3.g, kc, q3g); eb = rd_f16_gamma_value<HIST>(c3.b, kc, q3b);
+            hc0 = rd_pack_h2(er, eg); hc1 = rd_pack_h2(eb, 1.0f);
+            if (HIST && valid && has_b) count(q3r, q3g, q3b, 1u);
         } else if constexpr (F32T) {
             // One triple at a time: pinned gamma, codes into the histogram, r g b into the wave-private store stage
             // ([lane][c1, c2, c3]; the alphas are already there), so a finished triple holds no registers.  The stage still
@@ -679,13 +818,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             // a wave's LDS operations execute in order.
             rd_f4 *st = stage + (size_t)wave * 192u;
             const rd_rgb g1 = { rd_gamma_clamp(c1.r), rd_gamma_clamp(c1.g), rd_gamma_clamp(c1.b) };
-            if (HIST && valid && has_a) rd_hist_add(lh, copy, rd_q8(g1.r), rd_q8(g1.g), rd_q8(g1.b), 2u);
+            if (HIST && valid && has_a) count(rd_q8(g1.r), rd_q8(g1.g), rd_q8(g1.b), 2u);
             *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = g1;
             const rd_rgb g2 = { rd_gamma_clamp(c2.r), rd_gamma_clamp(c2.g), rd_gamma_clamp(c2.b) };
-            if (HIST && valid && has_b) rd_hist_add(lh, copy, rd_q8(g2.r), rd_q8(g2.g), rd_q8(g2.b), 1u);
+            if (HIST && valid && has_b) count(rd_q8(g2.r), rd_q8(g2.g), rd_q8(g2.b), 1u);
             *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 1u]) = g2;
             const rd_rgb g3 = { rd_gamma_clamp(c3.r), rd_gamma_clamp(c3.g), rd_gamma_clamp(c3.b) };
-            if (HIST && valid && has_b) rd_hist_add(lh, copy, rd_q8(g3.r), rd_q8(g3.g), rd_q8(g3.b), 1u);
+            if (HIST && valid && has_b) count(rd_q8(g3.r), rd_q8(g3.g), rd_q8(g3.b), 1u);
             *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = g3;
         } else if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
@@ -693,8 +832,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             q3r = rd_q8(c3.r); q3g = rd_q8(c3.g); q3b = rd_q8(c3.b);
         }
         if (HIST && valid && !H16 && !F32T) {
-            if (has_a) rd_hist_add(lh, copy, q1r, q1g, q1b, 2u);
-            if (has_b) { rd_hist_add(lh, copy, q2r, q2g, q2b, 1u); rd_hist_add(lh, copy, q3r, q3g, q3b, 1u); }
+            if (has_a) count(q1r, q1g, q1b, 2u);
+            if (has_b) { count(q2r, q2g, q2b, 1u); count(q3r, q3g, q3b, 1u); }
         }
         }   // !separable
         rd_tile_out<FMT> r;
@@ -708,12 +847,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         } else if constexpr (FMT == RD_FMT_RGBA_F16 && H16) {
             r.a0 = ha0; r.a1 = ha1; r.b0 = hb0; r.b1 = hb1; r.c0 = hc0; r.c1 = hc1;
         } else if constexpr (FMT == RD_FMT_RGBA_F16) {
-            const rd_h2 a_rg = { (_Float16)c1.r, (_Float16)c1.g }, a_b1 = { (_Float16)c1.b, (_Float16)1.0f };
-            const rd_h2 b_rg = { (_Float16)c2.r, (_Float16)c2.g }, b_b1 = { (_Float16)c2.b, (_Float16)1.0f };
-            const rd_h2 c_rg = { (_Float16)c3.r, (_Float16)c3.g }, c_b1 = { (_Float16)c3.b, (_Float16)1.0f };
-            r.a0 = __builtin_bit_cast(uint32_t, a_rg); r.a1 = __builtin_bit_cast(uint32_t, a_b1);
-            r.b0 = __builtin_bit_cast(uint32_t, b_rg); r.b1 = __builtin_bit_cast(uint32_t, b_b1);
-            r.c0 = __builtin_bit_cast(uint32_t, c_rg); r.c1 = __builtin_bit_cast(uint32_t, c_b1);
+            r.a0 = rd_pack_h2(c1.r, c1.g); r.a1 = rd_pack_h2(c1.b, 1.0f);
+            r.b0 = rd_pack_h2(c2.r, c2.g); r.b1 = rd_pack_h2(c2.b, 1.0f);
+            r.c0 = rd_pack_h2(c3.r, c3.g); r.c1 = rd_pack_h2(c3.b, 1.0f);
+        } else if constexpr (BITS) {                             // RGBA8 / RGB8 from the encodings: two byte permutes per pixel
+            r.v1 = rd_pack_rgba_bits<FMT == RD_FMT_RGBA_U8>(q1r, q1g, q1b);
+            r.v2 = rd_pack_rgba_bits<FMT == RD_FMT_RGBA_U8>(q2r, q2g, q2b);
+            r.v3 = rd_pack_rgba_bits<FMT == RD_FMT_RGBA_U8>(q3r, q3g, q3b);
         } else if constexpr (FMT == RD_FMT_RGB_U8) {
             r.v1 = q1r | (q1g << 8) | (q1b << 16);
             r.v2 = q2r | (q2g << 8) | (q2b << 16);
@@ -761,11 +901,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         } else if constexpr (FMT == RD_FMT_RGBA_F16) {
             RD_GLOBAL rd_u4 *o = reinterpret_cast<RD_GLOBAL rd_u4 *>(out);   // 2 px = 16 B per lane per row
             rd_u4 va = { r.a0, r.a1, r.a0, r.a1 }, vb = { r.b0, r.b1, r.c0, r.c1 };
-            if (!has_a) va = vb;
-            if (!has_b) vb = va;
-            if (valid) {
-                __builtin_nontemporal_store(va, o + (row_a_px >> 1) + q);
-                __builtin_nontemporal_store(vb, o + (row_b_px >> 1) + q);
+            if (__builtin_expect(!(has_a && has_b), 0)) {        // first / last unit only (wave-uniform): a BRANCH -- as selects
+                if (!has_a) va = vb; else vb = va;               // it cost every tile eight v_cndmask (the asm keeps it a branch)
+                asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+            }
+            if (valid) {                                         // wave-uniform base + the lane's own 16 bytes (see load_tile)
+                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)tq * 64u) + lane);
+                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)tq * 64u) + lane);
             }
         } else if constexpr (FMT == RD_FMT_RGB_U8) {
             // 2 px = 6 B per lane per row: repack the wave's 384-B rows through LDS (three 16-bit writes per
@@ -799,11 +941,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         } else {
             RD_GLOBAL rd_u2 *o = reinterpret_cast<RD_GLOBAL rd_u2 *>(out);   // 2 px = 8 B per lane per row
             rd_u2 va = { r.v1, r.v1 }, vb = { r.v2, r.v3 };
-            if (!has_a) va = vb;
-            if (!has_b) vb = va;
+            if (__builtin_expect(!(has_a && has_b), 0)) {        // first / last unit only (wave-uniform): a branch, not selects
+                if (!has_a) va = vb; else vb = va;
+                asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(vb.x), "+v"(vb.y));
+            }
             if (valid) {
-                __builtin_nontemporal_store(va, o + (row_a_px >> 1) + q);
-                __builtin_nontemporal_store(vb, o + (row_b_px >> 1) + q);
+                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)tq * 64u) + lane);
+                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)tq * 64u) + lane);
             }
         }
     };

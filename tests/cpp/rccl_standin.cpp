@@ -12,6 +12,7 @@
 // Build (tests/test_gpu_node_batch.py does it): hipcc -O1 -fPIC -shared -o tests/cpp/librccl_standin.so tests/cpp/rccl_standin.cpp
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <mutex>
@@ -39,6 +40,14 @@ std::mutex g_mu;
 int g_depth = 0;
 std::vector<pending> g_queue;
 unsigned long long g_calls = 0, g_groups = 0, g_max_ranks = 0;
+char g_why[256] = "stand-in: HIP call failed";
+
+int hip_fail(const char *what, hipError_t e)
+{
+    snprintf(g_why, sizeof g_why, "stand-in: %s failed: %s", what, hipGetErrorString(e));
+    return 1;
+}
+#define SI_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(#call, e_); } while (0)
 
 int flush()
 {
@@ -52,14 +61,14 @@ int flush()
     int prev = 0;
     (void)hipGetDevice(&prev);
     for (const pending &p : g_queue) {
-        if (hipSetDevice(p.c->device) != hipSuccess) return 1;
-        if (hipStreamSynchronize(p.stream) != hipSuccess) return 1;  // what was enqueued before the collective has run
-        if (hipMemcpy(part.data(), p.send, count * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        SI_HIP(hipSetDevice(p.c->device));
+        SI_HIP(hipStreamSynchronize(p.stream));                  // what was enqueued before the collective has run
+        SI_HIP(hipMemcpy(part.data(), p.send, count * sizeof(uint64_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < count; ++i) sum[i] += part[i];
     }
     for (const pending &p : g_queue) {
-        if (hipSetDevice(p.c->device) != hipSuccess) return 1;
-        if (hipMemcpy(p.recv, sum.data(), count * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return 1;
+        SI_HIP(hipSetDevice(p.c->device));
+        SI_HIP(hipMemcpy(p.recv, sum.data(), count * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     (void)hipSetDevice(prev);
     if (g_queue.size() > g_max_ranks) g_max_ranks = g_queue.size();
@@ -134,7 +143,7 @@ const char *ncclGetErrorString(int r)
 {
     switch (r) {
     case 0: return "no error";
-    case 1: return "stand-in: HIP call failed";
+    case 1: return g_why;
     case 4: return "stand-in: invalid argument (only u64 SUM all-reduce exists here)";
     case 5: return "stand-in: invalid usage (every rank of the communicator must join the group)";
     default: return "stand-in: unknown error";

@@ -31,6 +31,7 @@ def stats(standin):
 
 def main():
     path = os.environ["RAWDEV_RCCL_LIB"]
+    _lib.lib()                                                   # librawdev (and the HIP runtime it shares with the stand-in) first
     standin = C.CDLL(path)
     h, w = 132, 256
     total_calls = total_groups = 0

@@ -50,6 +50,28 @@ __global__ void __launch_bounds__(1024) k(float *out, float a, float b, int iter
                 if (KIND == 24) asm volatile("v_and_b32_e32 %0, 0x7fffff, %0" : "+v"(v));
                 if (KIND == 25) asm volatile("v_add_u32_e32 %0, 0x3f3504f3, %0" : "+v"(v));
                 if (KIND == 26) asm volatile("v_ashrrev_i32_e32 %0, 23, %0" : "+v"(v));
+                // round 3: the forms the narrow-surface kernels now use (tools/isa_budget.py's price list)
+                if (KIND == 27) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(v));
+                if (KIND == 28) asm volatile("v_log_f32_e32 %0, %0" : "+v"(v));
+                if (KIND == 29) asm volatile("v_exp_f32_e64 %0, %0 clamp" : "+v"(v));
+                if (KIND == 30) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(v) : "v"(bv), "s"(a));
+                if (KIND == 31) asm volatile("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(v) : "v"(bv));
+                if (KIND == 32) asm volatile("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(v) : "s"(a));
+                if (KIND == 33) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 34) asm volatile("v_cvt_u32_f32_e32 %0, %0" : "+v"(v));
+                if (KIND == 35) asm volatile("v_fract_f32_e32 %0, %0" : "+v"(v));
+                if (KIND == 36) asm volatile("v_cmp_gt_f32_e64 %1, |%0|, %2" : "+v"(v), "=s"(mask64) : "v"(bv));
+                if (KIND == 37) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 38) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 39) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 40) asm volatile("v_lshlrev_b32_e32 %0, 5, %0" : "+v"(v));
+                if (KIND == 41) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 42) asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(v));
+                if (KIND == 43) asm volatile("v_exp_f32_e32 %0, %0\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(v), "+v"(x[(i + 1) % ILP]) : "v"(av), "v"(bv));
+                if (KIND == 44) asm volatile("v_fma_f32 %0, |%0|, %1, %2 clamp" : "+v"(v) : "v"(av), "v"(bv));
+                if (KIND == 45) asm volatile("v_sub_u32_sdwa %0, %0, %1 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(v) : "v"(bv));
+                if (KIND == 46) asm volatile("v_cmp_gt_u32_e32 vcc, %1, %0" : : "v"(v), "v"(bv) : "vcc");
+                if (KIND == 47) asm volatile("v_cvt_f16_f32_e32 %0, %0" : "+v"(v));
             }
     }
     float s = 0;
@@ -69,7 +91,7 @@ static void run(const char *name, float *out)
     for (int r = 0; r < 4; ++r) hipLaunchKernelGGL((k<KIND, ILP>), dim3(blocks), dim3(1024), 0, 0, out, 0.999f, 0.001f, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 4;
-    const double instr = (double)blocks * 16 * ILP * 4 * iters * (KIND == 13 ? 2 : 1);     // wave-instructions
+    const double instr = (double)blocks * 16 * ILP * 4 * iters * (KIND == 13 ? 2 : KIND == 43 ? 4 : 1);     // wave-instructions
     printf("%-40s ILP %2d: %8.1f us  %6.2f ns per wave-instr per SIMD  (%5.2f T lane-op/s)\n", name, ILP, ms * 1e3,
            ms * 1e6 / (instr / 1024), instr * 64 / (ms * 1e-3) / 1e12);
 }
@@ -85,5 +107,10 @@ int main()
     R(11, "v_max_f32_e32 v,v"); R(12, "v_cvt_f32_u32_e32"); R(15, "v_cndmask_b32_e32 (vcc never written)"); R(16, "v_lshl_add_u32 (VOP3)"); R(17, "v_rndne_f32_e32");
     R(18, "v_cndmask_b32_e64 v,v,s[pair]"); R(19, "v_cmp_le + v_cndmask (2 instr, per pair)"); R(20, "v_cmp_le_f32 vcc"); R(21, "v_min_u32_e32");
     R(22, "v_min3_f32"); R(23, "v_div_fixup_f32"); R(24, "v_and_b32 literal"); R(25, "v_add_u32 literal"); R(26, "v_ashrrev_i32");
+    R(27, "v_exp_f32"); R(28, "v_log_f32"); R(29, "v_exp_f32_e64 clamp"); R(43, "v_exp_f32 + 3 v_fma_f32 (per instr, 4)");
+    R(30, "v_perm_b32 v,v,s"); R(31, "v_or_b32_sdwa v,v (WORD_1)"); R(32, "v_or_b32_sdwa v,s (WORD_1)"); R(42, "v_cvt_f32_u32_sdwa (WORD_1)");
+    R(45, "v_sub_u32_sdwa v,v clamp"); R(33, "v_cvt_pk_f16_f32"); R(47, "v_cvt_f16_f32"); R(34, "v_cvt_u32_f32"); R(35, "v_fract_f32");
+    R(36, "v_cmp_gt_f32_e64 s[pair],|v|,v"); R(46, "v_cmp_gt_u32_e32 vcc"); R(37, "v_max3_f32"); R(38, "v_med3_f32"); R(39, "v_mov_b32");
+    R(40, "v_lshlrev_b32"); R(41, "v_and_or_b32"); R(44, "v_fma_f32 |v|,v,v clamp");
     return 0;
 }
