@@ -118,8 +118,10 @@ __device__ __forceinline__ float rd_dot709_c(float r, float g, float b)      // 
 // and a few untouched sliders) sheds a quarter of the linear part.  Results are written back into r, g, b.
 // GAMMA = false stops before the gamma / clamp step (:261-264) and returns the linear values: the 8-bit surfaces finish
 // with rd_q8_gamma below.
-template <int N, int MATH, bool GAMMA = true>
-__device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
+// The front of the stack: white balance, temperature / tint, colour matrix (:195-214) -- the part in which a 2x2 block's three
+// triples share products (the compiler's common-subexpression pass finds them: 30 instead of 45 matrix instructions).
+template <int N, int MATH>
+__device__ __forceinline__ void rd_colour_front(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
 {
     constexpr bool C = MATH == RD_MATH_CONTRACTED;
     const uint32_t el = rd_elide_of(u);
@@ -145,6 +147,14 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
             r[i] = x; g[i] = y; b[i] = z;
         }
     }
+}
+
+// The rest: exposure ... vibrance (:217-257) and, with GAMMA, the gamma / clamp step (:261-264).
+template <int N, int MATH, bool GAMMA = true>
+__device__ __forceinline__ void rd_colour_tail(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
+{
+    constexpr bool C = MATH == RD_MATH_CONTRACTED;
+    const uint32_t el = rd_elide_of(u);
     if (!(el & RD_EL_EM)) {
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = r[i] * u.em; g[i] = g[i] * u.em; b[i] = b[i] * u.em; }            // :217-218
@@ -223,6 +233,13 @@ __device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float
 #pragma unroll
         for (int i = 0; i < N; ++i) { r[i] = rd_gamma_clamp(r[i]); g[i] = rd_gamma_clamp(g[i]); b[i] = rd_gamma_clamp(b[i]); }   // :261-264
     }
+}
+
+template <int N, int MATH, bool GAMMA = true>
+__device__ __forceinline__ void rd_colour_n(const rd_ku &u, float (&r)[N], float (&g)[N], float (&b)[N])
+{
+    rd_colour_front<N, MATH>(u, r, g, b);
+    rd_colour_tail<N, MATH, GAMMA>(u, r, g, b);
 }
 
 // The stack for a frame whose channel-mixing steps are all exact identities (RD_EL_SEPARABLE: identity matrix,

@@ -12,8 +12,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="--steps 2 --warmup 1 --frames 32 --no-cpu-baseline --no-alt-math"
-C5="--width 11648 --height 8736 --format f16 --row-bands 8 --frames 8 --ring 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math"
+BENCH="--steps 2 --warmup 1 --frames 32 --no-cpu-baseline --no-alt-math --no-extra"
+C5="--width 11648 --height 8736 --format f16 --row-bands 8 --frames 8 --ring 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-extra"
 pass() {   # name, env assignments ("-" for none), counters (comma separated), bench arguments...
   local name=$1 envs=$2 ctrs=$3; shift 3
   echo "== $name [$envs] $ctrs"
@@ -36,4 +36,7 @@ pass f32_multi_SQ1 - $SQ1 $BENCH
 pass f32_multi_SQ2 - $SQ2 $BENCH
 pass u8_multi_SQ1  - $SQ1 $BENCH --format u8
 pass f16_multi_SQ1 - $SQ1 $BENCH --format f16
+# the only "DRAM" counters rocprofv3 lists are the L2's fabric requests classified by DESTINATION
+# (profiles/r03_list_avail.txt); one pass shows whether they differ from the totals FETCH_SIZE / WRITE_SIZE derive from.
+pass f32_multi_DRAM - TCC_EA0_RDREQ_sum,TCC_EA0_RDREQ_DRAM_sum,TCC_EA0_WRREQ_sum,TCC_EA0_WRREQ_DRAM_sum,TCC_EA0_RDREQ_32B_sum,TCC_EA0_WRREQ_64B_sum $BENCH
 cd "$ROOT" && python3 tools/parse_pmc.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"

@@ -8,9 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" "$@" > "$OUT/$name.log" 2>&1
   rc=$?; echo "$name rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi; }
-run u8  --format u8  --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math
-run f16 --format f16 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math
-run c5  --width 11648 --height 8736 --format f16 --row-bands 8 --frames 64 --ring 4 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math
+run u8  --format u8  --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-extra
+run f16 --format f16 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-extra
+run c5  --width 11648 --height 8736 --format f16 --row-bands 8 --frames 64 --ring 4 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-extra
 cd "$ROOT"; python3 - "$OUT" <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]

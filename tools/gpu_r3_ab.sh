@@ -23,7 +23,7 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for fmt in u8 f16 f32; do
     ring=8; [ $fmt != f32 ] && ring=32
     for i in $(seq "$ROUNDS"); do
-        for lib in tools/librawdev_r3base.so raweditor_amd/librawdev.so; do
+        for lib in ${LIBS:-tools/librawdev_r3base.so raweditor_amd/librawdev.so}; do
             RAWDEV_LIB=$lib timeout -k 10 300 python bench.py --format $fmt --ring $ring --no-cpu-baseline --no-alt-math --no-extra --steps 10 2>>"$OUT/ab.err" \
                 | python -c "$pick" "$fmt $(basename $lib)" | tee -a "$OUT/ab.txt"
             rc=${PIPESTATUS[0]}; if [ $rc -ge 124 ]; then echo "bench killed: stopping"; exit $rc; fi

@@ -13,7 +13,9 @@ calibration"), in cycles per wave-instruction per SIMD:
     2  "full rate": v_fma / v_fmac / v_fmaak / v_fmamk / v_mul / v_add / v_sub f32 and the simple integer VOP2s
        (v_and / v_or / v_xor / v_add_u32 / v_sub_u32 / shifts / v_mov), all sources VGPR, literal or inline constant
     4  "half rate": the same with an SGPR source; v_max / v_min (f32, u32, 3-operand), v_cvt_*, v_rndne, v_fract,
-       v_cmp_*, v_cndmask, v_lshl_add / v_lshl_or / v_and_or / v_perm / v_bfe / v_mad_u32 (VOP3 integer), v_div_fixup
+       v_cmp_*, v_cndmask, v_lshl_add / v_lshl_or / v_and_or / v_perm / v_bfe / v_mad_u32 (VOP3 integer), v_div_fixup,
+       v_lshlrev_b32, every SDWA form, and the packed-f32 v_pk_mul / v_pk_add / v_pk_fma (two lane-operations in four
+       cycles: NO gain over two full-rate scalar instructions on this part -- profiles/r03_valu_probe.txt)
     8  "quarter rate": v_exp_f32 / v_log_f32 / v_rcp_f32 / v_rsq / v_sqrt
 
 Branch-conditional code inside the loop (the rare pinned-gamma fallback, the per-frame descriptor reload) is listed
@@ -35,7 +37,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectoriz
          "--cuda-device-only", "-gline-tables-only", "-S"]
 
 QUARTER = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
-HALF_OPS = re.compile(r"^v_(max|min|med3|max3|min3|cvt|rndne|fract|floor|ceil|trunc|cmp|cmpx|cndmask|lshl_add|lshl_or|and_or|or3|"
+HALF_OPS = re.compile(r"^v_(pk_|lshlrev_b32|max|min|med3|max3|min3|cvt|rndne|fract|floor|ceil|trunc|cmp|cmpx|cndmask|lshl_add|lshl_or|and_or|or3|"
                       r"add3|perm|bfe|bfi|mad_u32|mad_i32|mul_lo|mul_hi|div_fixup|div_scale|div_fmas|readlane|readfirstlane|"
                       r"writelane|alignbit|xad|add_lshl|mbcnt|sad|ldexp|frexp)")
 
@@ -68,9 +70,10 @@ def build_stage_table():
         return a, b
     rng(k, "rd_dot709(float r", "template <int M, int MATH>", "rd_kernels.h", "luma dot (highlights/shadows, saturation, vibrance)")
     rng(k, "template <int M, int MATH>", "rd_dot709_c(float r", "rd_kernels.h", "levels divide")
-    a, _ = rng(k, "rd_colour_n(const rd_ku &u", "if (!(el & RD_EL_K))", "rd_kernels.h", "white balance")
+    a, _ = rng(k, "rd_colour_front(const rd_ku &u", "if (!(el & RD_EL_K))", "rd_kernels.h", "white balance")
     rng(k, "if (!(el & RD_EL_K))", "if (!(el & RD_EL_MAT))", "rd_kernels.h", "temperature / tint", a)
-    rng(k, "if (!(el & RD_EL_MAT))", "if (!(el & RD_EL_EM))", "rd_kernels.h", "colour matrix", a)
+    rng(k, "if (!(el & RD_EL_MAT))", "// The rest: exposure ... vibrance", "rd_kernels.h", "colour matrix", a)
+    a = find(k, "rd_colour_tail(const rd_ku &u")
     rng(k, "if (!(el & RD_EL_EM))", "if ((el & (RD_EL_HL | RD_EL_SH))", "rd_kernels.h", "exposure", a)
     rng(k, "if ((el & (RD_EL_HL | RD_EL_SH))", "// :233-234", "rd_kernels.h", "highlights / shadows", a)
     a2 = find(k, "// :233-234", a)
@@ -104,7 +107,7 @@ def price(op, operands):
     """(cycles, class) of one VALU instruction."""
     if QUARTER.match(op):
         return 8, "quarter"
-    if HALF_OPS.match(op):
+    if HALF_OPS.match(op) or op.endswith("_sdwa"):
         return 4, "half"
     # an SGPR (or vcc / exec / m0) SOURCE halves the rate of the full-rate ops
     srcs = operands.split(",")[1:] if "," in operands else []

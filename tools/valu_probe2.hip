@@ -72,6 +72,19 @@ __global__ void __launch_bounds__(1024) k(float *out, float a, float b, int iter
                 if (KIND == 45) asm volatile("v_sub_u32_sdwa %0, %0, %1 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(v) : "v"(bv));
                 if (KIND == 46) asm volatile("v_cmp_gt_u32_e32 vcc, %1, %0" : : "v"(v), "v"(bv) : "vcc");
                 if (KIND == 47) asm volatile("v_cvt_f16_f32_e32 %0, %0" : "+v"(v));
+                // packed f32 (two lane-ops per instruction): plain, with op_sel broadcasts, with an inline constant
+                if (KIND >= 48 && KIND <= 54) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 &p = *reinterpret_cast<f2 *>(&x[i & ~1]);
+                    f2 ua = { av, bv }, ub = { bv, av };
+                    if (KIND == 48) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p) : "v"(ua));
+                    if (KIND == 49) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p) : "v"(ua));
+                    if (KIND == 50) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(p) : "v"(ua));
+                    if (KIND == 51) asm volatile("v_pk_add_f32 %0, %0, 1.0 op_sel_hi:[1,0]" : "+v"(p));
+                    if (KIND == 52) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "v"(ua), "v"(ub));
+                    if (KIND == 53) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]" : "+v"(p) : "v"(ua), "v"(ub));
+                    if (KIND == 54) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(p) : "v"(ua), "v"(ub));
+                }
             }
     }
     float s = 0;
@@ -112,5 +125,7 @@ int main()
     R(45, "v_sub_u32_sdwa v,v clamp"); R(33, "v_cvt_pk_f16_f32"); R(47, "v_cvt_f16_f32"); R(34, "v_cvt_u32_f32"); R(35, "v_fract_f32");
     R(36, "v_cmp_gt_f32_e64 s[pair],|v|,v"); R(46, "v_cmp_gt_u32_e32 vcc"); R(37, "v_max3_f32"); R(38, "v_med3_f32"); R(39, "v_mov_b32");
     R(40, "v_lshlrev_b32"); R(41, "v_and_or_b32"); R(44, "v_fma_f32 |v|,v,v clamp");
+    R(48, "v_pk_mul_f32 (per instr = 2 lane-ops)"); R(49, "v_pk_mul_f32 op_sel_hi:[1,0]"); R(50, "v_pk_mul_f32 op_sel:[0,1]");
+    R(51, "v_pk_add_f32 v, 1.0 op_sel_hi:[1,0]"); R(52, "v_pk_fma_f32"); R(53, "v_pk_fma_f32 op_sel:[0,1,0]"); R(54, "v_pk_fma_f32 op_sel_hi:[0,1,1] neg");
     return 0;
 }
