@@ -389,9 +389,9 @@ def extra_single_frame(torch, np, ra, dev, dev_index, cfa_t, p, stream, iters=60
     return {"config": "BASELINE configs[1]: single 24 MP RGGB frame, full 10-slider develop, f32 surface + fused histogram, "
                       "rd_render_device + synchronise per iteration",
             "iterations": len(host_us), "ms": round(med / 1e3, 5), "ms_min": round(min(host_us) / 1e3, 5),
-            "MP_per_s": round(W * H / med, 1), "kernel_us": round(kmed, 2),
-            "latency_note": "ms = median host-side time of launch + histogram fold + stream synchronise; kernel_us = median HIP-event "
-                            "time of the same enqueue (the roofline figure uses it)",
+            "MP_per_s": round(W * H / med, 1), "enqueue_us": round(kmed, 2),
+            "latency_note": "ms = median host-side time of launch + histogram fold + stream synchronise; enqueue_us = median HIP-event "
+                            "time of the same enqueue on its stream: the fused launch + the histogram fold + the gap between them (the roofline figure uses it: conservative; the launch alone is in profiles/r03_kernel_stats.csv)",
             "roofline": roofline_of("f32", W, H, kmed, "per_frame", "rd_develop_quads"),
             "verified": bool(ok), "verified_note": f"{info} row bands bit-identical to the oracle, histogram counts every pixel" if ok else str(info)}
 

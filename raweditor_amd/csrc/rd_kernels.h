@@ -551,6 +551,7 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 #ifndef RD_NUM_SGPR
 #define RD_NUM_SGPR 80
 #endif
+
 #ifdef RD_COLOUR_HOOK_HEADER  // tools/microbench.hip only: swaps in reduced-VALU stand-ins to find the memory floor
 #include RD_COLOUR_HOOK_HEADER
 #endif

@@ -213,7 +213,9 @@ def main():
     # instructions belong to a rarely executed source region (the pinned-gamma fallback of the shortcuts, the per-frame
     # descriptor reload, the per-frame sweep); everything in a cold block is listed apart, whatever line it came from
     # (the fallback's own rd_q8 pack lives in the same block as the pinned polynomials).
-    cold_stage = re.compile(r"^(frame change|pinned )")
+    # (the f32 surface evaluates the pinned pair for every value: there it is the hot path)
+    f32_surface = args.kernel.strip("<>").split(",")[0].strip() == "0"
+    cold_stage = re.compile(r"^(frame change)" if f32_surface else r"^(frame change|pinned )")
     blocks, cur, last_label = [], [], None
     for ins in loop:
         if ins["label"] != last_label and cur:
