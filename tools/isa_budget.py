@@ -31,7 +31,8 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# ISA_BUDGET_ROOT: another checkout of the sources (e.g. the previous round's, for a before / after pair)
+ROOT = os.environ.get("ISA_BUDGET_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "raweditor_amd", "csrc", "rawdev.hip")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17",
          "--cuda-device-only", "-gline-tables-only", "-S"]
@@ -58,10 +59,14 @@ def build_stage_table():
     m = open(mpath).read().splitlines()
 
     def find(lines, needle, start=0):
-        for i in range(start, len(lines)):
-            if needle in lines[i]:
-                return i + 1
-        raise SystemExit(f"marker not found: {needle}")
+        """1-based line of the first line at or after `start` that contains `needle` (a string, or a tuple of alternatives:
+        the round-3 spelling first, the round-2 one after it, so the tool also reads the previous round's sources)."""
+        needles = needle if isinstance(needle, tuple) else (needle,)
+        for n in needles:
+            for i in range(start, len(lines)):
+                if n in lines[i]:
+                    return i + 1
+        raise SystemExit(f"marker not found: {needles}")
 
     def rng(lines, first, last_excl, fname, name, start=0):
         a = find(lines, first, start)
@@ -70,10 +75,10 @@ def build_stage_table():
         return a, b
     rng(k, "rd_dot709(float r", "template <int M, int MATH>", "rd_kernels.h", "luma dot (highlights/shadows, saturation, vibrance)")
     rng(k, "template <int M, int MATH>", "rd_dot709_c(float r", "rd_kernels.h", "levels divide")
-    a, _ = rng(k, "rd_colour_front(const rd_ku &u", "if (!(el & RD_EL_K))", "rd_kernels.h", "white balance")
+    a, _ = rng(k, ("rd_colour_front(const rd_ku &u", "rd_colour_n(const rd_ku &u"), "if (!(el & RD_EL_K))", "rd_kernels.h", "white balance")
     rng(k, "if (!(el & RD_EL_K))", "if (!(el & RD_EL_MAT))", "rd_kernels.h", "temperature / tint", a)
-    rng(k, "if (!(el & RD_EL_MAT))", "// The rest: exposure ... vibrance", "rd_kernels.h", "colour matrix", a)
-    a = find(k, "rd_colour_tail(const rd_ku &u")
+    rng(k, "if (!(el & RD_EL_MAT))", ("// The rest: exposure ... vibrance", "if (!(el & RD_EL_EM))"), "rd_kernels.h", "colour matrix", a)
+    a = find(k, ("rd_colour_tail(const rd_ku &u", "rd_colour_n(const rd_ku &u"))
     rng(k, "if (!(el & RD_EL_EM))", "if ((el & (RD_EL_HL | RD_EL_SH))", "rd_kernels.h", "exposure", a)
     rng(k, "if ((el & (RD_EL_HL | RD_EL_SH))", "// :233-234", "rd_kernels.h", "highlights / shadows", a)
     a2 = find(k, "// :233-234", a)
@@ -83,8 +88,8 @@ def build_stage_table():
     rng(k, "if (!(el & RD_EL_VIB))", "if constexpr (GAMMA)", "rd_kernels.h", "vibrance", a)
     rng(k, "if constexpr (GAMMA)", "// The stack for a frame whose channel-mixing", "rd_kernels.h", "gamma call", a)
     rng(k, "rd_colour_separable(const rd_ku &u", "rd_colour_m(const rd_ku &u", "rd_kernels.h", "separable stack")
-    rng(k, "rd_norm(uint32_t raw", "// Rgba8Unorm quantisation (pipeline.rs:322)", "rd_kernels.h", "unpack + convert (u16 -> f32 / 4096)")
-    rng(k, "// Rgba8Unorm quantisation (pipeline.rs:322)", "#define RD_F16_KA", "rd_kernels.h", "gamma shortcut -> 8-bit code (rd_q8_gamma)")
+    rng(k, "rd_norm(uint32_t raw", ("// The same for black level 0", "// Rgba8Unorm quantisation (pipeline.rs:322)"), "rd_kernels.h", "unpack + convert (u16 -> f32 / 4096)")
+    rng(k, ("// The same for black level 0", "// Rgba8Unorm quantisation (pipeline.rs:322)"), "#define RD_F16_KA", "rd_kernels.h", "gamma shortcut -> 8-bit code (rd_q8_gamma)")
     rng(k, "#define RD_F16_KA", "// Histogram: RD_HK private copies", "rd_kernels.h", "gamma shortcut -> binary16 (rd_f16_gamma)")
     rng(k, "rd_hist_zero(uint32_t *lh)", "// Surface stores.  FMT is an rd_format", "rd_kernels.h", "histogram (addresses + LDS atomics)")
     rng(k, "auto adopt = [&]", "typedef uint32_t rd_u4 __attribute__", "rd_kernels.h", "frame change: uniforms (adopt)")

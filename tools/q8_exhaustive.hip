@@ -2,8 +2,8 @@
 // evaluation near a code boundary) against the pinned definition, for ALL 2^32 float encodings:
 //   (1) on the device:  rd_q8_gamma(x) == rd_q8(rd_gamma_clamp(x))                      (the product's own exact path)
 //   (2) on the host:    rd_q8_gamma(x) == (uint8)(clamp(ref_powf(x, 1/2.2)) * 255 + 0.5)   (the oracle's pow, clamp, pack)
-// and, for the choice of RD_Q8_EPS, the largest distance between the shortcut's y' = 255 * 2^(log2(x)/2.2) + 0.5 and the
-// pinned y over every encoding, and how many encodings take the pinned evaluation.
+// and, for the choice of RD_Q8_EPS, the largest distance between the shortcut's 255 * clamp(2^(log2(x)/2.2)) and the
+// pinned 255 * gamma(x) over every encoding, and how many encodings take the pinned evaluation.
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Ioracle -o tools/q8_exhaustive \
 //         tools/q8_exhaustive.hip -Loracle -ldevelop_ref -Wl,-rpath,\$ORIGIN/../oracle -pthread
 //   tools/q8_exhaustive [--device-only]
@@ -36,11 +36,12 @@ __global__ void __launch_bounds__(256) k(uint32_t base, uint8_t *out8, q8_stats 
         atomicMin(&st->first_bad, base + i);
     }
     if (x >= RD_FLT_MIN) {                                        // the shortcut's own intermediate, for the statistics
-        float y = __builtin_fmaf(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * RD_INV_GAMMA), 255.0f, 0.5f);
-        y = __builtin_fminf(y, 255.5f);
-        const float ye = rd_gamma_clamp(x) * 255.0f + 0.5f;
-        const float d = __builtin_fabsf(y - ye);
-        if (__builtin_fabsf(__builtin_amdgcn_fractf(y) - 0.5f) > 0.5f - RD_Q8_EPS) atomicAdd(&st->fallbacks, 1ull);
+        float z;
+        const float e = rd_hw_gamma01(x, z);                      // round 3: clamped hardware pow, add-magic code, distance to the tie
+        const float t = __builtin_fmaf(e, 255.0f, RD_MAGIC23);
+        const float dn = __builtin_fmaf(e, 255.0f, -(t - RD_MAGIC23));
+        if (__builtin_fabsf(dn) > 0.5f - RD_Q8_EPS) atomicAdd(&st->fallbacks, 1ull);
+        const float d = __builtin_fabsf(e * 255.0f - rd_gamma_clamp(x) * 255.0f);
         // atomicMax on the bits: d >= 0, so the integer order is the float order
         atomicMax(reinterpret_cast<uint32_t *>(&st->max_dist), rd_f2u(d));
     }
