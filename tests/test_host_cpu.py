@@ -191,6 +191,47 @@ def test_export_kernel_register_budget():
         build.check_resources({"rd_develop_quads<x>": {"vgprs": 72, "sgprs": 78, "scratch": 0}})
 
 
+def test_narrow_surface_instruction_budget():
+    """The RGBA8 and RGBA-f16 export kernels are bound by VALU issue ('Instruction budget'), so their
+    per-tile instruction count is a property worth guarding like the register budget: tools/isa_budget.py compiles the kernel
+    with the bench workload's path pinned, reads hipcc's own assembly and prices the main loop.  Round 3's figures: RGBA8
+    343 VALU / 862 issue cycles per tile (round 2: 397 / 1124), f16 408 / 1030 (488 / 1404).  No half-rate conversion
+    (v_cvt_u32_f32, v_fract_f32) and no v_cndmask may come back into the hot path of the RGBA8 gamma shortcut."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_budget
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not found")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "rawdev.s")
+        subprocess.run([hipcc] + isa_budget.FLAGS + ["-DRD_BUDGET_ELIDE=128u", "-o", asm, isa_budget.SRC], check=True,
+                       stderr=subprocess.DEVNULL)
+        limits = {"<2,true,true,0,false>": (360, 900), "<1,true,true,0,false>": (420, 1060)}
+        for kernel, (max_valu, max_cycles) in limits.items():
+            listing = os.path.join(td, "loop.txt")
+            out = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_budget.py"), "--asm", asm, "--kernel", kernel,
+                                  "--listing", listing], capture_output=True, text=True, check=True).stdout
+            m = re.search(r"TOTAL per tile \(hot path\)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)", out)
+            assert m, out
+            valu, full, half, sgpr, quarter, cycles = map(int, m.groups())
+            assert valu <= max_valu and cycles <= max_cycles, (kernel, valu, cycles)
+            assert quarter == 18, (kernel, quarter)                          # nine v_log_f32 + nine v_exp_f32, nothing else
+            hot = [ln for ln in open(listing) if not ln.startswith("C")]
+            assert sum("v_exp_f32" in ln and "clamp" in ln for ln in hot) == 9, kernel     # the clamp rides on v_exp_f32
+            if kernel.startswith("<2"):
+                assert not any(re.search(r"v_cvt_u32_f32|v_fract_f32|v_cndmask", ln) for ln in hot), kernel
+                assert sum("v_perm_b32" in ln for ln in hot) == 6, kernel                  # two byte permutes per pixel
+            else:
+                assert sum("v_cvt_pk_f16_f32" in ln for ln in hot) == 6, kernel            # two packed conversions per pixel
+
+
 def test_elided_steps_flags():
     """Host-side proof logic of the identity-step elision (rd_uniforms.h RD_EL_*), no device needed: untouched sliders
     and the identity matrix are flagged, touched ones are not, and nothing that relies on finiteness is flagged when an

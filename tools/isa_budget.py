@@ -88,8 +88,8 @@ def build_stage_table():
     rng(k, "if (!(el & RD_EL_VIB))", "if constexpr (GAMMA)", "rd_kernels.h", "vibrance", a)
     rng(k, "if constexpr (GAMMA)", "// The stack for a frame whose channel-mixing", "rd_kernels.h", "gamma call", a)
     rng(k, "rd_colour_separable(const rd_ku &u", "rd_colour_m(const rd_ku &u", "rd_kernels.h", "separable stack")
-    rng(k, "rd_norm(uint32_t raw", ("// The same for black level 0", "// Rgba8Unorm quantisation (pipeline.rs:322)"), "rd_kernels.h", "unpack + convert (u16 -> f32 / 4096)")
-    rng(k, ("// The same for black level 0", "// Rgba8Unorm quantisation (pipeline.rs:322)"), "#define RD_F16_KA", "rd_kernels.h", "gamma shortcut -> 8-bit code (rd_q8_gamma)")
+    rng(k, "rd_norm(uint32_t raw", "// Rgba8Unorm quantisation (pipeline.rs:322)", "rd_kernels.h", "unpack + convert (u16 -> f32 / 4096)")
+    rng(k, "// Rgba8Unorm quantisation (pipeline.rs:322)", "#define RD_F16_KA", "rd_kernels.h", "gamma shortcut -> 8-bit code (rd_q8_gamma)")
     rng(k, "#define RD_F16_KA", "// Histogram: RD_HK private copies", "rd_kernels.h", "gamma shortcut -> binary16 (rd_f16_gamma)")
     rng(k, "rd_hist_zero(uint32_t *lh)", "// Surface stores.  FMT is an rd_format", "rd_kernels.h", "histogram (addresses + LDS atomics)")
     rng(k, "auto adopt = [&]", "typedef uint32_t rd_u4 __attribute__", "rd_kernels.h", "frame change: uniforms (adopt)")
@@ -97,6 +97,14 @@ def build_stage_table():
     rng(k, "auto load_tile = [&]", "// demosaic + colour stack + histogram of one tile", "rd_kernels.h", "CFA loads")
     rng(k, "auto compute_tile = [&]", "rd_tile_out<FMT> r;", "rd_kernels.h", "demosaic select / triple assembly / unpack")
     rng(k, "rd_tile_out<FMT> r;", "// surface stores of one tile.", "rd_kernels.h", "pack")
+    # the first / last unit's missing-row select sits behind a wave-uniform branch (2 of H/2+1 units): rare
+    sa = find(k, "auto store_tile = [&]")
+    for needle in ("first / last unit only (wave-uniform): a BRANCH", "first / last unit only (wave-uniform): a branch, not selects"):
+        try:
+            e0 = find(k, needle, sa)
+            stages.append((e0, e0 + 3, "rd_kernels.h", "frame edge: missing-row select"))
+        except SystemExit:
+            pass
     rng(k, "auto store_tile = [&]", "if (tile < ntiles) {", "rd_kernels.h", "surface stores")
     rng(k, "auto prefetch_frame = [&]", "// Software pipeline, one tile deep", "rd_kernels.h", "frame change: sweep")
     rng(k, "// Software pipeline, one tile deep", "// One frame, or one row band of a frame", "rd_kernels.h", "tile bookkeeping (loop)")
@@ -220,7 +228,7 @@ def main():
     # (the fallback's own rd_q8 pack lives in the same block as the pinned polynomials).
     # (the f32 surface evaluates the pinned pair for every value: there it is the hot path)
     f32_surface = args.kernel.strip("<>").split(",")[0].strip() == "0"
-    cold_stage = re.compile(r"^(frame change)" if f32_surface else r"^(frame change|pinned )")
+    cold_stage = re.compile(r"^(frame change|frame edge)" if f32_surface else r"^(frame change|frame edge|pinned )")
     blocks, cur, last_label = [], [], None
     for ins in loop:
         if ins["label"] != last_label and cur:
