@@ -721,6 +721,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     auto load_tile = [&](uint32_t pu, uint32_t pq, uint32_t &top, uint32_t &bot) {
         const uint32_t ra = pu ? 2u * pu - 1u : 0u;
         const uint32_t rb = 2u * pu < H ? 2u * pu : H - 1u;
+#ifdef RD_PROBE_NO_TILE_LOADS                                    // probe builds only (tools/): what the main loop's loads cost the memory system
+        (void)ra; (void)rb; top = lane * 0x00010001u + pu; bot = top ^ 0x01230123u; return;
+#endif
         if constexpr (FULL) {
             // wave-uniform base (SALU, 64-bit) + the lane's own dword: global_load_dword v_lane4, s[base] -- no per-tile
             // 64-bit VALU address arithmetic (it was 14 issue cycles per tile, tools/isa_budget.py)
@@ -1081,6 +1084,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             }
         };
 
+#ifdef RD_SWEEP_ALL                                              // experiment: every frame of the launch swept at launch start
+        if constexpr (MULTI && BURST) { for (uint32_t f = 1; f < nframes; ++f) prefetch_frame(f); }
+#endif
         // Software pipeline, one tile deep on each side:
         //   iteration i:  issue loads(i+1) | store tile i-1 (registers -> LDS transpose -> HBM) | compute tile i
         // vmcnt retires in order, so waiting for loads(i+1) only requires the stores of tile i-2 to
@@ -1097,7 +1103,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 if (MULTI && f != fr_n) {                    // the load stage enters another frame
                     fr_n = f;
                     cfa = (const RD_GLOBAL uint16_t *)descs[f].cfa;
+#ifndef RD_SWEEP_ALL
                     if (BURST) prefetch_frame(f);            // this wave's share of the frame's sweep
+#endif
                 }
             }
         };
