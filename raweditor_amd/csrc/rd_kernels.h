@@ -1103,10 +1103,24 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 if (MULTI && f != fr_n) {                    // the load stage enters another frame
                     fr_n = f;
                     cfa = (const RD_GLOBAL uint16_t *)descs[f].cfa;
-#ifndef RD_SWEEP_ALL
+#if !defined(RD_SWEEP_ALL) && !defined(RD_SWEEP_ROLLING)
                     if (BURST) prefetch_frame(f);            // this wave's share of the frame's sweep
 #endif
                 }
+#ifdef RD_SWEEP_ROLLING                                          // experiment: the NEXT frame's plane swept piece by piece, in address
+                if (MULTI && BURST && f + 1u < nframes && !(tin & 1u)) {       // order, as the ticket front moves through this frame
+                    const uint32_t piece = tin >> 1;
+                    if (piece < (uint32_t)(((size_t)H * W * sizeof(uint16_t)) >> 10)) {
+                        const char *sb = reinterpret_cast<const char *>(descs[f + 1u].cfa) + ((size_t)piece << 10);
+                        const uint32_t dump = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&pf_dump[0]));
+                        const uint32_t voff = lane * 16u;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dump), "v"(voff), "s"(sb) : "memory", "m0");
+#pragma clang diagnostic pop
+                    }
+                }
+#endif
             }
         };
         next_tile();
