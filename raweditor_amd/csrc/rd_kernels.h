@@ -1067,7 +1067,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         // frame with the sweep at frame entry, 84.1 us without any sweep of the later frames; starting the sweep
         // earlier (when the load stage stands at 90 ... 99 % of the PREVIOUS frame's tiles) was no better
         // (79.3 ... 80.1), much earlier (50 ... 75 %) worse: the sweep then holds back the stores of the tiles in
-        // flight.  The threshold variant is gone; "at frame entry" is what remains.
+        // flight.  The threshold variant is gone; "at frame entry" is what remains.  Round 3 tried the two other extremes --
+        // every frame of the launch swept at launch start, and the next frame's plane swept piece by piece in address
+        // order as the ticket front moves through the current one -- both slower (profiles/r03_memory_floor.txt).
         auto prefetch_frame = [&](uint32_t fr) {
             const char *base = reinterpret_cast<const char *>(descs[fr].cfa);
             const uint32_t n1k = (uint32_t)(((size_t)H * W * sizeof(uint16_t)) >> 10);   // whole 1-KiB pieces of a plane
@@ -1084,9 +1086,6 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             }
         };
 
-#ifdef RD_SWEEP_ALL                                              // experiment: every frame of the launch swept at launch start
-        if constexpr (MULTI && BURST) { for (uint32_t f = 1; f < nframes; ++f) prefetch_frame(f); }
-#endif
         // Software pipeline, one tile deep on each side:
         //   iteration i:  issue loads(i+1) | store tile i-1 (registers -> LDS transpose -> HBM) | compute tile i
         // vmcnt retires in order, so waiting for loads(i+1) only requires the stores of tile i-2 to
@@ -1103,24 +1102,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 if (MULTI && f != fr_n) {                    // the load stage enters another frame
                     fr_n = f;
                     cfa = (const RD_GLOBAL uint16_t *)descs[f].cfa;
-#if !defined(RD_SWEEP_ALL) && !defined(RD_SWEEP_ROLLING)
                     if (BURST) prefetch_frame(f);            // this wave's share of the frame's sweep
-#endif
                 }
-#ifdef RD_SWEEP_ROLLING                                          // experiment: the NEXT frame's plane swept piece by piece, in address
-                if (MULTI && BURST && f + 1u < nframes && !(tin & 1u)) {       // order, as the ticket front moves through this frame
-                    const uint32_t piece = tin >> 1;
-                    if (piece < (uint32_t)(((size_t)H * W * sizeof(uint16_t)) >> 10)) {
-                        const char *sb = reinterpret_cast<const char *>(descs[f + 1u].cfa) + ((size_t)piece << 10);
-                        const uint32_t dump = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void *)(&pf_dump[0]));
-                        const uint32_t voff = lane * 16u;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dump), "v"(voff), "s"(sb) : "memory", "m0");
-#pragma clang diagnostic pop
-                    }
-                }
-#endif
             }
         };
         next_tile();
