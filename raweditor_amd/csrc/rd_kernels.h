@@ -551,6 +551,9 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 #ifndef RD_NUM_SGPR
 #define RD_NUM_SGPR 80
 #endif
+#ifndef RD_SWEEP_POLICY
+#define RD_SWEEP_POLICY ""      // cache-policy bits of the sweeps' LDS-DMA loads (probe builds: " nt", " sc1", ...)
+#endif
 
 #ifdef RD_COLOUR_HOOK_HEADER  // tools/microbench.hip only: swaps in reduced-VALU stand-ins to find the memory floor
 #include RD_COLOUR_HOOK_HEADER
@@ -1033,14 +1036,14 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                              "global_load_dword %1, %3, off\n\t"
                              "s_mov_b32 m0, %4\n\t"
                              "s_nop 0\n\t"
-                             "global_load_lds_dwordx4 %5, off\n\t"
-                             "global_load_lds_dwordx4 %6, off\n\t"
-                             "global_load_lds_dwordx4 %7, off\n\t"
-                             "global_load_lds_dwordx4 %8, off\n\t"
-                             "global_load_lds_dwordx4 %9, off\n\t"
-                             "global_load_lds_dwordx4 %10, off\n\t"
-                             "global_load_lds_dwordx4 %11, off\n\t"
-                             "global_load_lds_dwordx4 %12, off\n\t"
+                             "global_load_lds_dwordx4 %5, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %6, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %7, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %8, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %9, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %10, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %11, off" RD_SWEEP_POLICY "\n\t"
+                             "global_load_lds_dwordx4 %12, off" RD_SWEEP_POLICY "\n\t"
                              "s_waitcnt vmcnt(8)"
                              : "=&v"(top), "=&v"(bot)
                              : "v"(pt), "v"(pb), "s"(lds_base), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]),
@@ -1081,7 +1084,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 const char *sb = base + ((size_t)piece << 10);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dump), "v"(voff), "s"(sb) : "memory", "m0");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" RD_SWEEP_POLICY ::"s"(dump), "v"(voff), "s"(sb) : "memory", "m0");
 #pragma clang diagnostic pop
             }
         };
