@@ -237,6 +237,9 @@ public:
         return h;
     }
     void synchronize() { check(rd_node_batch_synchronize(h_)); }
+    // measurement aids: the hipStream_t devices[index]'s share is enqueued on; fused launches of its share of the last call
+    void *stream(uint32_t index) const { return rd_node_batch_stream(h_, index); }
+    uint32_t last_launch_count(uint32_t index = 0) const { return rd_node_batch_last_launch_count(h_, index); }
 
 private:
     std::vector<int> devices_;
