@@ -557,6 +557,19 @@ def run_ranks(args):
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
                          "steps alternate between two frame arrays (slider stacks of the two batch halves swapped): every step "
                          "uploads its descriptors")
+    if world > 1 and with_hist:
+        # the all-reduce latency on its own (outside the timed region): 768 x i64 over RCCL, median of 20
+        lat = []
+        with torch.cuda.stream(stream):
+            for _ in range(25):
+                barrier()
+                t1 = time.perf_counter()
+                allreduce_histogram(hist)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e6)
+        lat = sorted(lat[5:])
+        result["allreduce_us"] = {"median": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1), "bytes": 768 * 8, "backend": backend,
+                                  "note": "one all-reduce of the 768 x i64 histogram + synchronise, host-timed on rank 0, after a barrier"}
     if world == 1 and not args.no_alt_math:
         # Reported-only: the same workload in the other arithmetic, 5 steps.
         other = "contracted" if args.math == "strict" else "strict"
@@ -683,6 +696,16 @@ def run_node(args):
                          ("; REHEARSAL: a device is listed more than once, the ranks share one GPU" if dup else ""),
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
                          "steps alternate between two frame arrays: every step uploads its descriptors")
+    if with_hist:
+        # the histogram call on its own (per-device fold + all-reduce over RCCL when N > 1 + read-back + synchronise), idle devices
+        lat = []
+        for _ in range(25):
+            t1 = time.perf_counter()
+            nb.histogram()
+            lat.append((time.perf_counter() - t1) * 1e6)
+        lat = sorted(lat[5:])
+        result["histogram_call_us"] = {"median": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1), "reduction": nb.reduce_kind(),
+                                       "note": "rd_node_batch_histogram on idle devices: fold kernels + reduction + 6 KiB read-back + synchronise"}
     if N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
     print(json.dumps(result), flush=True)

@@ -37,6 +37,7 @@ def test_bare_multi_gpu_call_launches_its_own_ranks(gpu_lib):
     assert r["config"]["frames_per_gpu"] == 8 and r["scaling"] == "weak"
     assert r["value"] > 0 and r["roofline"]["frac"] > 0
     assert "extra_configs" not in r and "cpu_baseline" not in r      # N = 1 only
+    assert r["allreduce_us"]["median"] > 0 and r["allreduce_us"]["bytes"] == 6144     # reported separately
 
 
 def test_node_host_mode_one_process(gpu_lib):
@@ -44,6 +45,7 @@ def test_node_host_mode_one_process(gpu_lib):
                {"RD_NODE_REDUCE": "host"})
     assert r["n_gpus"] == 2 and r["verified"] is True
     assert "rd_node_batch" in r["config"]["host"] and "REHEARSAL" in r["config"]["host"]
+    assert r["histogram_call_us"]["median"] > 0 and "host fold" in r["histogram_call_us"]["reduction"]
     r1 = _bench(["--host", "node", "--gpus", "1", "--frames", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
     assert r1["n_gpus"] == 1 and r1["verified"] is True and "REHEARSAL" not in r1["config"]["host"]
 
