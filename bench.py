@@ -385,11 +385,24 @@ def extra_single_frame(torch, np, ra, dev, dev_index, cfa_t, p, stream, iters=60
     med, kmed = statistics.median(host_us), statistics.median(kern_us)
     ok, info = check_bands("f32", W, H, cfa_t, p, out, "strict", "single frame")
     ok = ok and int(hist.sum().item()) == 3 * W * H
+    # "randomised + default stacks" -- the same loop with EditParams::default() (edit.rs:81-95)
+    pipe.update_uniforms(ra.EditParams())
+    dflt = []
+    with torch.cuda.stream(stream):
+        for it in range(iters):
+            t0 = time.perf_counter()
+            pipe.render_device(W, H, ra.FMT_RGBA_F32, out.data_ptr(), hist.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            dflt.append((time.perf_counter() - t0) * 1e6)
+    dmed = statistics.median(dflt[10:])
+    ok_d, _ = check_bands("f32", W, H, cfa_t, ra.EditParams(), out, "strict", "single frame, default stack")
+    ok = ok and ok_d
     pipe.close()
-    return {"config": "BASELINE configs[1]: single 24 MP RGGB frame, full 10-slider develop, f32 surface + fused histogram, "
-                      "rd_render_device + synchronise per iteration",
+    return {"config": "BASELINE configs[1]: single 24 MP RGGB frame, full 10-slider develop (randomised stack; the default stack beside it), "
+                      "f32 surface + fused histogram, rd_render_device + synchronise per iteration",
             "iterations": len(host_us), "ms": round(med / 1e3, 5), "ms_min": round(min(host_us) / 1e3, 5),
             "MP_per_s": round(W * H / med, 1), "enqueue_us": round(kmed, 2),
+            "ms_default_stack": round(dmed / 1e3, 5), "MP_per_s_default_stack": round(W * H / dmed, 1),
             "latency_note": "ms = median host-side time of launch + histogram fold + stream synchronise; enqueue_us = median HIP-event "
                             "time of the same enqueue on its stream: the fused launch + the histogram fold + the gap between them (the roofline figure uses it: conservative; the launch alone is in profiles/r03_kernel_stats.csv)",
             "roofline": roofline_of("f32", W, H, kmed, "per_frame", "rd_develop_quads"),
