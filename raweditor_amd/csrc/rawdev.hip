@@ -571,7 +571,7 @@ static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_
     int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
                                hist_dev != nullptr, p->math_mode, l.slab32, nullptr, 0, l.tq, s, &blocks);
     if (rc == RD_OK && hist_dev) {
-        hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, s, l.slab32, blocks, hist_dev);
+        hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, s, l.slab32, blocks, hist_dev);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "histogram fold launch failed: %s", hipGetErrorString(e));
     }
@@ -657,7 +657,7 @@ extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, p->stream, (const uint32_t *)p->out_buf,
                        (uint32_t)npx, l.slab32);
-    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(256), 0, p->stream, l.slab32, blocks, p->hist_dev);
+    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, p->stream, l.slab32, blocks, p->hist_dev);
     const hipError_t le = hipGetLastError();
     p->scratch.used(l, p->stream, le != hipSuccess);
     RD_HIP(le);
@@ -976,7 +976,7 @@ extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
     if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
-    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(256), 0, (hipStream_t)stream, b->slab64,
+    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(RD_FOLD_THREADS), 0, (hipStream_t)stream, b->slab64,
                        b->blocks * b->n_streams, (unsigned long long *)hist_dev);
     RD_HIP(hipGetLastError());
     return RD_OK;

@@ -1256,15 +1256,19 @@ rd_hist_u8(const uint32_t *__restrict__ rgba, uint32_t npx, uint32_t *slab32)
 }
 
 // Fold the per-workgroup slab rows: block b owns bins [32b, 32b+32), thread (g, j) sums rows g, g+8, ...
-// of bin 32b+j; the 8 partial sums per bin meet in LDS.  Launch: 24 blocks x 256 threads.
+// of bin 32b+j; the partial sums per bin meet in LDS.  Launch: 24 blocks x RD_FOLD_THREADS threads (round 3: 1024
+// instead of 256 -- the fold sits behind every single-frame render with a histogram, and a thread's chain of dependent row
+// loads was most of its 11.5 us).
+#define RD_FOLD_THREADS 1024     // 32 bins x 32 row groups: a thread sums at most RD_MAX_BLOCKS / 32 rows (16 of a 512-row slab)
 template <typename T>
 __device__ __forceinline__ T rd_fold_bins(T *__restrict__ slab, uint32_t nblocks, bool clear)
 {
-    __shared__ T part[8][32];
+    constexpr uint32_t NG = RD_FOLD_THREADS / 32u;
+    __shared__ T part[NG][32];
     const uint32_t j = threadIdx.x & 31u, g = threadIdx.x >> 5;
     const uint32_t bin = blockIdx.x * 32u + j;
     T sum = 0;
-    for (uint32_t w = g; w < nblocks; w += 8u) {
+    for (uint32_t w = g; w < nblocks; w += NG) {
         sum += slab[(size_t)w * 768u + bin];
         if (clear) slab[(size_t)w * 768u + bin] = 0;
     }
@@ -1273,13 +1277,13 @@ __device__ __forceinline__ T rd_fold_bins(T *__restrict__ slab, uint32_t nblocks
     T tot = 0;
     if (g == 0) {
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) tot += part[k][j];
+        for (uint32_t k = 0; k < NG; ++k) tot += part[k][j];
     }
     return tot;
 }
 
 // out32[bin] = sum over workgroups of slab32[wg][bin]
-__global__ void __launch_bounds__(256) rd_reduce_slab32(uint32_t *__restrict__ slab32, uint32_t nblocks,
+__global__ void __launch_bounds__(RD_FOLD_THREADS) rd_reduce_slab32(uint32_t *__restrict__ slab32, uint32_t nblocks,
                                                         uint32_t *__restrict__ out32)
 {
     const uint32_t tot = rd_fold_bins<uint32_t>(slab32, nblocks, false);
@@ -1287,7 +1291,7 @@ __global__ void __launch_bounds__(256) rd_reduce_slab32(uint32_t *__restrict__ s
 }
 
 // out64[bin] = sum over workgroups of slab64[wg][bin]; the slab is zeroed for the next batch.
-__global__ void __launch_bounds__(256) rd_reduce_slab64(unsigned long long *__restrict__ slab64, uint32_t nblocks,
+__global__ void __launch_bounds__(RD_FOLD_THREADS) rd_reduce_slab64(unsigned long long *__restrict__ slab64, uint32_t nblocks,
                                                         unsigned long long *__restrict__ out64)
 {
     const unsigned long long tot = rd_fold_bins<unsigned long long>(slab64, nblocks, true);
