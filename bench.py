@@ -43,6 +43,7 @@ SEED = 0x52415745
 WB = (2.0, 1.0, 1.5, 1.0)
 CM = (1.6, -0.4, -0.2, -0.3, 1.5, -0.2, 0.0, -0.5, 1.5)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_COPY_GBPS = 6290.0           # MI355X_MICROARCH.md: what a streaming copy reaches on this part ("~6.3 TB/s achievable")
 BYTES_PER_PX = {"f32": 18, "f16": 10, "u8": 6}   # 2 B CFA read + surface write
 
 
@@ -341,6 +342,7 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": traffic_source,
+            "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBPS, 4),      # reported beside `frac`, never instead of it
             "kernel": "rd_develop_batch" if multi else "rd_develop_quads",
             "launch_us": round(launch_us, 2), "frames_per_launch": round(F / lpc, 3), "us_per_frame": round(frame_us, 2),
             "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
