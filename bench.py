@@ -71,6 +71,7 @@ def parse_args(argv=None):
                     help="skip the short extra run in the other math mode (reported under 'alt_math', N=1 only)")
     ap.add_argument("--no-extra", action="store_true", help="skip 'extra_configs' (config 1, RGBA8, config-5 shape; N=1 only)")
     ap.add_argument("--no-hist", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the box's own copy / fill ceiling (roofline.box_*, ~0.1 s before the headline)")
     ap.add_argument("--data", choices=["uniform", "gradient"], default="uniform",
                     help="uniform: i.i.d. 12-bit samples (SURVEY 8d, the headline); gradient: smooth ramp + 1 %% noise "
                          "(SURVEY 8d's second distribution: flat regions, same-bin histogram atomics, less bit toggling)")
@@ -181,7 +182,15 @@ def cpu_baseline(width, height, budget_s):
     cfa = rng.integers(0, 4096, (height, width), dtype=np.uint16)
     p = EditParams.random(np.random.default_rng([SEED, 1]))
     u = ref_c.make_uniforms({f: getattr(p, f) for f in FIELDS}, WB, CM)
-    L = ref_c.lib()
+    # SURVEY 8d builds the baseline "-O3 -march=native, contraction off": that flavour is compiled on THIS machine
+    # (oracle/Makefile `native`; -march=native code does not travel) and is bit-identical to the portable -O2 checker
+    # (tests/test_oracle_kat.py).  If it cannot be built here the portable build is timed and the line says so.
+    flavour = "-O3 -march=native -ffp-contract=off -fno-fast-math (built on this host)"
+    try:
+        L = ref_c.lib_native()
+    except Exception as e:  # noqa: BLE001
+        L = ref_c.lib()
+        flavour = f"-O2 -mfma -ffp-contract=off (portable checker build; the native build failed: {e})"
     cp = cfa.ctypes.data_as(C.POINTER(C.c_uint16))
     fr, sec = C.c_int(), C.c_double()
     L.ref_bench_mt(cp, width, height, C.byref(u), cores, float(budget_s), 4096, C.byref(fr), C.byref(sec))
@@ -190,6 +199,11 @@ def cpu_baseline(width, height, budget_s):
     band_h = min(256, height)
     L.ref_bench_mt(cp, width, band_h, C.byref(u), 1, min(2.0, float(budget_s)), 64, C.byref(fr), C.byref(sec))
     one_thread = fr.value * width * band_h / 1e6 / sec.value
+    # the portable -O2 build (what rounds 1-3 reported) beside it, briefly
+    portable = None
+    if L is not ref_c.lib():
+        ref_c.lib().ref_bench_mt(cp, width, height, C.byref(u), cores, min(3.0, float(budget_s)), 4096, C.byref(fr), C.byref(sec))
+        portable = round(fr.value * width * height / 1e6 / sec.value, 2)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -203,6 +217,7 @@ def cpu_baseline(width, height, budget_s):
     return {"value": round(mpps, 2), "unit": "MP/s", "cores": cores, "kind": "port",
             "one_thread_MPps": round(one_thread, 2),
             "parallel_efficiency": round(mpps / (one_thread * cores), 3),
+            "build": flavour, "value_portable_O2_build": portable,
             "sample": f"{frames} x {width}x{height} frame(s), randomised stack, f32 surface, {el:.1f} s on {cores} "
                       f"persistent threads with first-touch row bands ({model}; {cores_note}); scalar f32 port of the shader, no SIMD: "
                       f"arithmetic-bound (one thread: {one_thread:.1f} MP/s), reported-only"}
@@ -216,7 +231,7 @@ def check_bands(fmt_name, W, H, cfa_t, p, surf_t, math_name, label):
     math_mode = ref_c.MATH_CONTRACTED if math_name == "contracted" else ref_c.MATH_STRICT
     mid = (H // 2) | 1
     bands = [(0, min(6, H)), (max(0, min(1001, H - 6)), min(1007, H)), (mid, min(mid + 2, H)), (max(0, H - 6), H)]
-    bpp = {"f32": 16, "f16": 8, "u8": 4}[fmt_name]
+    bpp = {"f32": 16, "f16": 8, "u8": 4, "rgb8": 3}[fmt_name]
     cfa = cfa_t.cpu().numpy().view(np.uint16)
     u = ref_c.make_uniforms({f: getattr(p, f) for f in FIELDS}, WB, CM, math_mode=math_mode)
     rows = surf_t.view(H, W * bpp)
@@ -227,6 +242,8 @@ def check_bands(fmt_name, W, H, cfa_t, p, surf_t, math_name, label):
             ok = np.array_equal(raw.view(np.uint32).reshape(r1 - r0, W, 4), exp.view(np.uint32))
         elif fmt_name == "f16":
             ok = np.array_equal(raw.view(np.uint16).reshape(r1 - r0, W, 4), ref_c.pack_f16(exp).view(np.uint16))
+        elif fmt_name == "rgb8":
+            ok = np.array_equal(raw.reshape(r1 - r0, W, 3), ref_c.pack_u8(exp)[..., :3])
         else:
             ok = np.array_equal(raw.reshape(r1 - r0, W, 4), ref_c.pack_u8(exp))
         if not ok:
@@ -268,6 +285,70 @@ def pmc_traffic(fmt_name, W, H, mode):
     return None, None
 
 
+
+# ------------------------------------------------------------------------------------------------
+# what ran where: per-rank identity + timings, gathered on rank 0 (the first real multi-GPU run cannot be repeated
+# interactively, so its line must say by itself which devices the ranks were on and how each of them did)
+# ------------------------------------------------------------------------------------------------
+DIAG_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "NCCL_DEBUG",
+            "RCCL_MSCCL_ENABLE", "NCCL_SOCKET_IFNAME", "NCCL_P2P_DISABLE", "RAWDEV_DIST_BACKEND", "RD_BATCH_MAX_FRAMES", "RD_BATCH_PERSISTENT")
+
+
+def rank_record(rank, local_rank, dev_index, ident, elapsed_s, dev_ms, steps, frames, width, height, launches_per_step, box):
+    """One rank's own account of the timed region (its own wall clock and its own HIP events)."""
+    wall_ms = elapsed_s * 1e3 / steps
+    return {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "pci_bus_id": ident.get("pci_bus_id"),
+            "name": ident.get("name"), "host": socket.gethostname(), "pid": os.getpid(),
+            "ms_per_step": round(wall_ms, 4), "ms_per_step_hip_events": round(dev_ms / steps, 4),
+            "launches": launches_per_step * steps, "us_per_frame": round(dev_ms * 1e3 / (steps * frames), 3),
+            "MP_per_s": round(frames * width * height / 1e3 / wall_ms, 1),
+            "box_copy_GBps": box.get("copy"), "box_fill_GBps": box.get("fill")}
+
+
+def summarize_ranks(records, world_env, world_seen, backend):
+    """rank 0's view of all ranks: (fields for the JSON line, error text or None).  Under nccl (= RCCL) two ranks on one
+    device mean the run did not measure N GPUs: that is an error, not a number."""
+    recs = sorted(records, key=lambda r: r["rank"])
+    ids = [(r.get("host"), r.get("pci_bus_id") or f"index:{r.get('device_index')}") for r in recs]
+    distinct = len(set(ids))
+    mp = [r["MP_per_s"] for r in recs]
+    out = {"ranks": recs, "world_size_seen": world_seen, "world_size_env": world_env, "distinct_devices": distinct,
+           "per_gpu_MPps_min": min(mp), "per_gpu_MPps_max": max(mp),
+           "per_gpu_MPps_spread": round((max(mp) - min(mp)) / max(mp), 4) if max(mp) > 0 else None,
+           "env": {k: os.environ.get(k) for k in DIAG_ENV}}
+    err = None
+    if world_seen != world_env or len(recs) != world_env:
+        err = f"world size mismatch: WORLD_SIZE={world_env}, process group reports {world_seen}, {len(recs)} rank records gathered"
+    elif backend == "nccl" and distinct < len(recs):
+        dup = sorted({i for i in ids if ids.count(i) > 1})
+        err = (f"{len(recs)} ranks ran on {distinct} distinct device(s) (shared: {dup}): under nccl every rank must own its GPU; "
+               "this run did not measure N GPUs")
+    return out, err
+
+
+def device_identity(dev_index):
+    import ctypes as C
+    from raweditor_amd import _lib
+    buf = C.create_string_buffer(64)
+    name = C.create_string_buffer(128)
+    try:
+        _lib.check(_lib.lib().rd_device_identity(dev_index, buf, len(buf), name, len(name)))
+        return {"pci_bus_id": buf.value.decode() or None, "name": name.value.decode() or None}
+    except Exception as e:  # noqa: BLE001
+        return {"pci_bus_id": None, "name": f"unknown ({e})"}
+
+
+def measure_box(ra, dev_index):
+    """The box's own streaming ceilings, before the headline and outside its timed region ('measured
+    hipMemcpyDtoD/stream-triad ceiling on the box'): librawdev's float4 copy / nt fill / read kernels over 1 GiB, median of 5."""
+    try:
+        t0 = time.perf_counter()
+        c, f, r = ra.measure_hbm(dev_index, 1 << 30, 5)
+        return {"copy": round(c, 1), "fill": round(f, 1), "read": round(r, 1), "seconds": round(time.perf_counter() - t0, 2)}
+    except Exception as e:  # noqa: BLE001
+        return {"copy": None, "fill": None, "read": None, "error": str(e)}
+
+
 def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform"):
     """Synthetic frames generated on the device, keyed by (seed, global frame index = first_index + f * stride)."""
     cfas, params = [], []
@@ -303,7 +384,7 @@ def workload_label(W, H, world, F):
     return "custom frame size"
 
 
-def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, verified_note, host_note, descriptors_note):
+def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, verified_note, host_note, descriptors_note, box=None):
     total_px = float(world) * F * W * H * args.steps
     launches = args.steps * lpc
     launch_us = dev_ms * 1e3 / launches                    # avg fused-launch period incl. gaps and folds
@@ -313,6 +394,7 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
     multi = lpc < F * max(1, args.row_bands)
     per_frame, traffic_source = pmc_traffic(args.format, W, H, "multi" if multi else "per_frame")
     traffic = int(per_frame * F / lpc) if per_frame is not None else None       # per launch, like `achieved`
+    box = box or {}
     return {
         "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
         "value": round(total_px / 1e6 / elapsed, 1),
@@ -343,6 +425,11 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": traffic_source,
             "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBPS, 4),      # reported beside `frac`, never instead of it
+            # this box, this run, before the headline (rd_measure_hbm: float4 copy / nt fill / read of 1 GiB, median of 5)
+            "box_copy_GBps": box.get("copy"), "box_fill_GBps": box.get("fill"), "box_read_GBps": box.get("read"),
+            "frac_of_box_copy": round(achieved / box["copy"], 4) if box.get("copy") else None,
+            "frac_of_box_fill": round(achieved / box["fill"], 4) if box.get("fill") else None,
+            "box_note": "the guide's 6290 GB/s copy figure stays in frac_of_copy_ceiling; box_* are measured on this device in this run",
             "kernel": "rd_develop_batch" if multi else "rd_develop_quads",
             "launch_us": round(launch_us, 2), "frames_per_launch": round(F / lpc, 3), "us_per_frame": round(frame_us, 2),
             "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
@@ -411,14 +498,26 @@ def extra_single_frame(torch, np, ra, dev, dev_index, cfa_t, p, stream, iters=60
             "verified": bool(ok), "verified_note": f"{info} row bands bit-identical to the oracle, histogram counts every pixel" if ok else str(info)}
 
 
-def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, ring_n, row_bands, steps, stream, label, kernel_mode):
-    """A batch workload on another surface format / frame size, timed like the headline (HIP events, descriptors alternate)."""
+def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, ring_n, row_bands, steps, stream, label, kernel_mode,
+                tiled=False):
+    """A batch workload on another surface format / frame size, timed like the headline (HIP events, descriptors alternate).
+    tiled: RD_BATCH_PERSISTENT=0 for this context -- every frame is `row_bands` separate row-band launches (BASELINE
+    config 5's "tiled multi-launch per frame"); by default the multi-frame launch needs no bands of its own and ignores them."""
     fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8}[fmt_name]
     bpp = ra.BYTES_PER_PIXEL[fmt]
     F = len(cfas)
     ring = [torch.empty(H * W * bpp, dtype=torch.uint8, device=dev) for _ in range(ring_n)]
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
-    be = ra.BatchExporter(dev_index, W, H, fmt, True)
+    saved = os.environ.get("RD_BATCH_PERSISTENT")
+    if tiled:
+        os.environ["RD_BATCH_PERSISTENT"] = "0"              # read by rd_batch_create
+    try:
+        be = ra.BatchExporter(dev_index, W, H, fmt, True)
+    finally:
+        if tiled:
+            os.environ.pop("RD_BATCH_PERSISTENT", None)
+            if saved is not None:
+                os.environ["RD_BATCH_PERSISTENT"] = saved
     variants = [params, swapped_halves(params)]
     arrays = [be.make_frames([c.data_ptr() for c in cfas], [ring[i % ring_n].data_ptr() for i in range(F)], v, WB, CM)
               for v in variants]
@@ -445,15 +544,111 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     be.close()
     del ring
     return {"config": label, "frames": F, "steps": steps, "ms": round(ms / steps, 4), "us_per_frame": round(us, 2),
-            "MP_per_s": round(W * H / us, 1), "launches_per_step": lpc, "out_ring": ring_n, "row_bands": row_bands,
-            "roofline": roofline_of(fmt_name, W, H, us, kernel_mode, "rd_develop_batch"),
+            "MP_per_s": round(W * H / us, 1), "launches_per_step": lpc, "out_ring": ring_n, "row_bands_requested": row_bands,
+            # what ran: the multi-frame launch sweeps a frame in row order and cuts no bands of its own
+            "row_bands_effective": row_bands if lpc >= F * max(1, row_bands) else 1,
+            "frames_per_launch": round(F / lpc, 3),
+            "roofline": roofline_of(fmt_name, W, H, us, kernel_mode, "rd_develop_quads" if lpc >= F else "rd_develop_batch"),
             "verified": bool(ok), "verified_note": note}
 
+
+
+def extra_full_res_to_bytes(torch, np, ra, dev, dev_index, cfa_t, p, iters=24):
+    """The reference's own metric-path ENTRY as its caller invokes it: RenderPipeline::render_full_res_to_bytes
+    (pipeline.rs:526-606, called from export_image_async, main.rs:1749-1754) -- kernel + read-back of the 96.6 MB RGBA8
+    surface into host memory, per call, PCIe included.  Three destinations: page-locked (rd_host_alloc: direct DMA), a
+    pageable buffer the caller reuses, and a fresh pageable buffer per call (what returning a new Vec<u8> costs: its
+    first-touch page faults).  The PCIe floor beside them is measured here: one pinned D2H copy of the same bytes."""
+    import statistics
+    H, W = cfa_t.shape
+    nbytes = W * H * 4
+    pipe = ra.RenderPipeline.from_device(2, cfa_t.data_ptr(), W, H, p, WB, CM, device=dev_index)
+    pin = ra.PinnedBytes(nbytes, dev_index)
+    reused = np.empty(nbytes, np.uint8)
+    reused[:] = 0                                             # touched once: its pages exist
+
+    def run(make_dst):
+        ms = []
+        for it in range(iters + 4):
+            dst = make_dst()
+            t0 = time.perf_counter()
+            out = pipe.render_full_res_to_bytes(out=dst)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        ms = ms[4:]
+        return out, statistics.median(ms), min(ms)
+
+    res, ok_all, notes = {}, True, []
+    for name, make_dst, limiter in (
+            ("pinned_dst", lambda: pin.array, "PCIe (the DMA engine writes the caller's page-locked buffer directly)"),
+            ("pageable_dst_reused", lambda: reused, "PCIe or the staging memcpy, whichever is slower on this host (8 MiB pinned slots -> caller's "
+                                                    "buffer on RD_COPY_THREADS helper threads, overlapped with the next chunk's DMA)"),
+            ("pageable_dst_fresh", lambda: None, "first-touch page faults of the new 96.6 MB buffer (taken inside the staging memcpy) -- the cost of "
+                                                 "returning a fresh Vec<u8> per call, as the reference's signature does")):
+        out, med, mn = run(make_dst)
+        ok, info = check_bands("u8", W, H, cfa_t, p, torch.from_numpy(out), "strict", name)
+        ok_all = ok_all and ok
+        if not ok:
+            notes.append(str(info))
+        res[name] = {"ms": round(med, 3), "ms_min": round(mn, 3), "GBps_over_pcie": round(nbytes / med / 1e6, 1),
+                     "MP_per_s": round(W * H / med / 1e3, 1), "limiter": limiter}
+    # the floor: the same bytes, device -> page-locked host, one hipMemcpyAsync on a stream, nothing else
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    fl = []
+    for _ in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        fl.append((time.perf_counter() - t0) * 1e3)
+    floor = statistics.median(fl[2:])
+    pipe.close()
+    pin.free()
+    del src, dst
+    return {"config": "RenderPipeline::render_full_res_to_bytes as export_image_async calls it (pipeline.rs:526-606, main.rs:1749-1754): "
+                      f"one {W}x{H} frame, RGBA8, kernel + read-back into host memory per call (PCIe-inclusive: never `value`)",
+            "iterations": iters, "bytes": nbytes, **res,
+            "pcie_floor_ms": round(floor, 3), "pcie_floor_GBps": round(nbytes / floor / 1e6, 1),
+            "pcie_floor_note": "one page-locked D2H copy of the same 96.6 MB, measured in this run",
+            "reference_published": "\"SLOW (1-2 seconds for 24MP)\", pipeline.rs:525 / main.rs:1752-1753, unspecified hardware",
+            "verified": bool(ok_all), "verified_note": "4 row bands of every destination bit-identical to the oracle" if ok_all else "; ".join(notes)}
+
+
+def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
+    """the export feed for a STREAM of frames (rd_exporter_*: kernel of frame i+1 under the D2H of frame i,
+    pinned ring), RGB8 = the reference's JPEG path with its CPU alpha strip (main.rs:1777-1786) fused into the kernel."""
+    H, W = cfas[0].shape
+    out = {}
+    for name, fmt, fname in (("rgb8", ra.FMT_RGB_U8, "rgb8"), ("rgba8", ra.FMT_RGBA_U8, "u8")):
+        ex = ra.Exporter(dev_index, W, H, fmt, n_slots=3)
+        frames = [ex.frame(cfas[i % len(cfas)].data_ptr(), params[i % len(cfas)], WB, CM) for i in range(n_frames)]
+        for _ in ex.export(frames[:6]):
+            pass
+        keep = None
+        t0 = time.perf_counter()
+        n = 0
+        for i, surf in ex.export(frames):
+            n += 1
+            if i == n_frames - 1:
+                keep = np.array(surf, copy=True)
+        dt = time.perf_counter() - t0
+        i_last = (n_frames - 1) % len(cfas)
+        ok, info = check_bands(fname, W, H, cfas[i_last], params[i_last], torch.from_numpy(keep.reshape(-1)), "strict", f"export ring {name}")
+        nbytes = W * H * ra.BYTES_PER_PIXEL[fmt]
+        out[name] = {"ms_per_frame": round(dt / n * 1e3, 3), "frames_per_s": round(n / dt, 1), "MP_per_s": round(n * W * H / dt / 1e6, 1),
+                     "GBps_over_pcie": round(n * nbytes / dt / 1e9, 1), "frames": n, "slots": 3,
+                     "verified": bool(ok), "verified_note": f"{info} row bands of the last frame bit-identical to the oracle" if ok else str(info)}
+        ex.close()
+    out["config"] = (f"export ring (rd_exporter_*): {n_frames} x {W}x{H} frames resident in HBM -> fused develop -> pinned host ring, "
+                     "PCIe-inclusive; RGB8 = JPEG feed (alpha strip fused), RGBA8 = PNG feed")
+    return out
 
 def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream):
     out = {}
     t0 = time.perf_counter()
     out["single_frame_f32"] = extra_single_frame(torch, np, ra, dev, dev_index, cfas[0], params[0], stream)
+    out["full_res_to_bytes"] = extra_full_res_to_bytes(torch, np, ra, dev, dev_index, cfas[1], params[1])
+    out["export_ring"] = extra_export_ring(torch, np, ra, dev, dev_index, cfas[:8], params[:8])
     n8 = len(cfas)
     out["batch_rgba8"] = extra_batch(torch, np, ra, dev, dev_index, "u8", cfas[:n8], params[:n8], 6016, 4016, 32, 1, 6, stream,
                                      f"the reference's own surface (Rgba8Unorm, pipeline.rs:322) on the batch workload: {n8} x 6016x4016, "
@@ -462,7 +657,12 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream):
     c5, p5 = make_batch(torch, np, ra, dev, W5, H5, 16, 1 << 20, 1)
     out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 6, stream,
                                            "BASELINE configs[4] shape on one GPU: 16 x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
-                                           "row_bands 8, randomised stacks, fused histogram, strict f32 arithmetic", "multi")
+                                           "randomised stacks, fused histogram, strict f32 arithmetic; default launch mode: multi-frame "
+                                           "launches (4 frames each, capped by the ring of 4), which sweep a frame in row order and "
+                                           "need no row bands of their own", "multi")
+    out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3, stream,
+                                                 "the same 16 x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
+                                                 "8 row-band launches per frame (RD_BATCH_PERSISTENT=0)", "per_frame", tiled=True)
     del c5
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
@@ -488,7 +688,10 @@ def run_ranks(args):
     # RAWDEV_DIST_BACKEND=gloo is a rehearsal mode for a 1-GPU box: several ranks share device 0 and the
     # histogram all-reduce goes over gloo (RCCL refuses two ranks on one device).  The driver's runs use nccl.
     backend = os.environ.get("RAWDEV_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    # nccl: one GPU per rank.  A launcher that narrows each rank's view to one device (HIP_VISIBLE_DEVICES per rank) leaves
+    # index 0 as that rank's own GPU; whether two ranks ended up on ONE physical device is checked from the PCI bus ids below.
+    dev_index = local_rank if local_rank < ndev else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -505,6 +708,8 @@ def run_ranks(args):
     bpp_out = ra.BYTES_PER_PIXEL[fmt]
     with_hist = not args.no_hist
 
+    ident = device_identity(dev_index)
+    box = measure_box(ra, dev_index) if not args.no_box else {}       # before the headline, outside its timed region (~0.1 s)
     cfas, params = make_batch(torch, np, ra, dev, W, H, F, rank, world, args.data)     # frame i -> rank i mod N
     ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
@@ -545,11 +750,25 @@ def run_ranks(args):
         barrier()
         elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                         # HIP events on the launch stream
+    elapsed_own = elapsed
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # every rank's own account of the region, gathered on rank 0 (N = 1: the one record)
+    mine = rank_record(rank, local_rank, dev_index, ident, elapsed_own, dev_ms, args.steps, F, W, H, max(1, be.last_launch_count()), box)
+    records, diag_err = [mine], None
+    world_seen = 1
+    if world > 1:
+        world_seen = dist.get_world_size()
+        try:
+            gathered = [None] * world_seen
+            dist.all_gather_object(gathered, mine)
+            records = [r for r in gathered if r is not None]
+        except Exception as e:  # noqa: BLE001  (the headline must survive a failed gather; the line then says so)
+            diag_err = f"rank records could not be gathered: {type(e).__name__}: {e}"
 
     if with_hist:                                          # sanity: the global histogram counts every pixel
         got = int(hist.sum().item())
@@ -567,19 +786,33 @@ def run_ranks(args):
     # RD_BATCH_PERSISTENT=0 gives one launch per frame / row band).  Algorithmic bytes per launch = SURVEY 8(d)'s
     # per-pixel figure x the pixels one launch processes.
     lpc = max(1, be.last_launch_count())
+    unmeasured = ("; N > 1 on DISTINCT devices had never run before this line was produced on a multi-GPU node -- check "
+                  "`distinct_devices` == n_gpus" if world > 1 else "")
     result = result_line(args, world, F, W, H, elapsed, dev_ms, lpc, len(ring), verified, verified_note,
-                         "one process per GPU (torch.distributed, backend " + (backend if world > 1 else "none: single rank") + ")",
+                         "one process per GPU (torch.distributed, backend " + (backend if world > 1 else "none: single rank") + ")" + unmeasured,
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
                          "steps alternate between two frame arrays (slider stacks of the two batch halves swapped): every step "
-                         "uploads its descriptors")
+                         "uploads its descriptors", box=box)
+    if rank == 0:
+        # as-nccl: the duplicate-device rule applies to this run (nccl always; RAWDEV_DIAG_ASSUME_NCCL=1 lets the gloo
+        # rehearsal on a one-GPU box prove that the rule fires)
+        rule_backend = "nccl" if (backend == "nccl" or os.environ.get("RAWDEV_DIAG_ASSUME_NCCL") == "1") else backend
+        diag, err2 = summarize_ranks(records, world, world_seen, rule_backend)
+        result.update(diag)
+        result["backend"] = backend if world > 1 else None
+        diag_err = diag_err or err2
+        if diag_err:
+            result["invalid"] = diag_err
     if world > 1 and with_hist:
         # the all-reduce latency on its own (outside the timed region): 768 x i64 over RCCL, median of 20
         lat = []
+        scratch = torch.zeros_like(hist)                   # not `hist`: 25 in-place sums would grow it by world^25
         with torch.cuda.stream(stream):
             for _ in range(25):
+                scratch.zero_()
                 barrier()
                 t1 = time.perf_counter()
-                allreduce_histogram(hist)
+                allreduce_histogram(scratch)
                 torch.cuda.synchronize()
                 lat.append((time.perf_counter() - t1) * 1e6)
         lat = sorted(lat[5:])
@@ -615,12 +848,20 @@ def run_ranks(args):
             result["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
+    failed = False
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        if result.get("invalid"):                          # not a measurement of N GPUs: stderr + non-zero exit, no stdout line
+            print("bench.py: INVALID RUN: " + result["invalid"], file=sys.stderr)
+            print(json.dumps(result), file=sys.stderr, flush=True)
+            failed = True
+        else:
+            print(json.dumps(result), flush=True)
     be.close()
     if world > 1:
         dist.barrier()                                     # rank 0 spent a second on the oracle check: leave together
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -638,7 +879,7 @@ def run_node(args):
     if N > ndev:
         # a rehearsal on a smaller box: a device listed several times; librawdev accepts that only with RD_NODE_REDUCE=host
         # (histograms folded on the host) or with the test stand-in for librccl
-        if os.environ.get("RD_NODE_REDUCE") != "host" and not os.environ.get("RAWDEV_RCCL_LIB"):
+        if os.environ.get("RD_NODE_REDUCE") not in ("host", "standin"):
             sys.exit(f"--host node --gpus {N}: only {ndev} device(s) visible (RD_NODE_REDUCE=host rehearses N > devices on one GPU)")
     devices = [d % ndev for d in range(N)]
     W, H, F = args.width, args.height, args.frames
@@ -657,6 +898,8 @@ def run_node(args):
     for d in set(devices):
         torch.cuda.synchronize(d)
     nb = ra.NodeBatch(devices, W, H, fmt, with_hist, math_mode=math_mode)
+    idents = [device_identity(d) for d in devices]
+    box = measure_box(ra, devices[0]) if not args.no_box else {}
 
     def frame_array(swap):
         cp, op, pp = [], [], []
@@ -710,7 +953,11 @@ def run_node(args):
                          f"histogram reduction: {nb.reduce_kind()}; each step = develop + histogram (synchronises)" +
                          ("; REHEARSAL: a device is listed more than once, the ranks share one GPU" if dup else ""),
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
-                         "steps alternate between two frame arrays: every step uploads its descriptors")
+                         "steps alternate between two frame arrays: every step uploads its descriptors", box=box)
+    result["devices"] = [{"slot": i, "device_index": d, "pci_bus_id": idents[i].get("pci_bus_id"), "name": idents[i].get("name"),
+                          "launches": nb.last_launch_count(i) * args.steps} for i, d in enumerate(devices)]
+    result["distinct_devices"] = len({(i.get("pci_bus_id") or f"index:{d}") for i, d in zip(idents, devices)})
+    result["env"] = {k: os.environ.get(k) for k in DIAG_ENV + ("RD_NODE_REDUCE", "RAWDEV_RCCL_LIB")}
     if with_hist:
         # the histogram call on its own (per-device fold + all-reduce over RCCL when N > 1 + read-back + synchronise), idle devices
         lat = []

@@ -30,8 +30,12 @@ extern "C" {
 
 /* ABI history.  1: round 1.  2: rd_frame gained `matrix_layout` (the struct grew by one u32); rd_batch_develop packs several
  * frames into one launch; new entry points rd_node_batch_*, rd_batch_plan_launches, rd_batch_last_launch_count,
- * rd_pipeline_set_matrix_layout, rd_selftest_q8 / _f16 (+ _codes / _halves), rd_ljpeg_decode, rd_stream_*, rd_debug_*. */
-#define RD_ABI_VERSION 2
+ * rd_pipeline_set_matrix_layout, rd_selftest_q8 / _f16 (+ _codes / _halves), rd_ljpeg_decode, rd_stream_*, rd_debug_*.
+ * 3: no signature changed.  Host renders no longer serialise on the pipeline (each call takes a render lane; the mutex only
+ * guards the uniforms) and a full-resolution render is band-pipelined (see rd_render_full_res_to_bytes); new entry points
+ * rd_host_alloc / rd_host_free (page-locked render destinations), rd_measure_hbm (the box's own streaming ceilings),
+ * rd_device_identity. */
+#define RD_ABI_VERSION 3
 
 typedef enum rd_status {
     RD_OK = 0,
@@ -97,6 +101,9 @@ typedef struct rd_batch rd_batch;
 int rd_abi_version(void);              /* returns RD_ABI_VERSION (not a status) */
 const char *rd_last_error(void);       /* thread-local, never NULL */
 int rd_device_count(int *count);       /* number of visible HIP devices */
+/* PCI bus id ("0000:c1:00.0") and name of visible device `device` (either buffer may be NULL): what tells the ranks of a
+ * multi-GPU run apart (bench.py prints it per rank and refuses a run in which two ranks share a device). */
+int rd_device_identity(int device, char *pci_bus_id, size_t pci_cap, char *name, size_t name_cap);
 /* EditParams::default() (edit.rs:81-95): all 0 except whites = 1. */
 void rd_edit_params_default(rd_edit_params *p);
 /* preview / histogram target sizes with the reference's truncating f32 arithmetic (pipeline.rs:125-133). */
@@ -143,7 +150,18 @@ int rd_update_uniforms_with_zoom(rd_pipeline *p, const rd_edit_params *params, f
 /* render_to_bytes (pipeline.rs:442-522): preview_width x preview_height RGBA8 with the current
  * uniforms (zoom/pan included). dst_len must be preview_w*preview_h*4. */
 int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
-/* render_full_res_to_bytes (pipeline.rs:526-606): width x height RGBA8, current uniforms. */
+/* render_full_res_to_bytes (pipeline.rs:526-606; the export path, main.rs:1749-1754): width x height RGBA8, current
+ * uniforms.  The reference renders, copies the texture to a MAP_READ buffer, blocks in poll(Wait) and de-pads 96.6 MB
+ * row by row ("SLOW (1-2 seconds for 24MP)", pipeline.rs:525).  Here the frame is launched as row bands whose bytes
+ * cross PCIe while the later bands are still computed.  `dst` may be any host memory:
+ *   - page-locked (rd_host_alloc, hipHostMalloc, hipHostRegister; detected per call): the DMA engine writes it directly --
+ *     the call costs the PCIe transfer (about 1.8 ms for 24 MP) and nothing else;
+ *   - pageable (a Vec<u8>, malloc): the bytes pass through a small pinned staging ring and are moved into `dst` by a few
+ *     helper threads (RD_COPY_THREADS, default 4) while the next chunk is in flight; first-touch page faults of a fresh
+ *     buffer are the caller's and dominate (INTEGRATION.md section 2 has the numbers).
+ * The call does NOT hold the pipeline's lock while it runs: a concurrent rd_render_to_bytes / rd_update_uniforms from the
+ * UI thread proceeds on another render lane (the uniforms are snapshotted when the call starts -- like the reference, the
+ * export uses whatever view() wrote last, main.rs:1515 vs :1754). */
 int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
 /* render_to_histogram_bytes (pipeline.rs:615-716): histogram_width x histogram_height RGBA8. */
 int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
@@ -153,7 +171,9 @@ int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_t rgba_len,
 
 /* General form of the three renders: any target size and surface format, current uniforms.
  * `hist` (nullable) receives the fused 3x256 histogram of the 8-bit quantised output -- the same
- * counts rd_calculate_histogram would give on the U8 surface of this render. */
+ * counts rd_calculate_histogram would give on the U8 surface of this render.  Up to four host renders of one pipeline
+ * run at the same time (one render lane each); a fifth waits for a lane.  Whole-frame targets of 16 MiB and more take the
+ * band-pipelined read-back described at rd_render_full_res_to_bytes. */
 int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t format, void *dst,
               size_t dst_len, uint32_t hist[768]);
 /* Device-resident variant: `dst_dev` (and nullable `hist_dev`, 768 x u32) are device pointers on
@@ -218,9 +238,10 @@ int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);
  * The only exchange is the global histogram: ncclAllReduce(768, ncclUint64, ncclSum) over RCCL (librccl.so is loaded on
  * first use, and only when n_devices > 1); with one device there is no communicator.
  * Environment: RD_NODE_REDUCE=host folds the per-device histograms on the host instead (and then accepts a device
- * listed twice: a rehearsal of N > 1 on a one-GPU box); RD_NODE_REDUCE=rccl builds a communicator even for one device;
- * RAWDEV_RCCL_LIB names the library file (it wins over a copy the process has already mapped; when it names the test
- * stand-in tests/cpp/rccl_standin.cpp, a device may also be listed twice). */
+ * listed twice: a rehearsal of N > 1 on a one-GPU box); RD_NODE_REDUCE=rccl builds a communicator even for one device.
+ * One RCCL per process: a librccl the process has already mapped (a PyTorch host) is used as it is; otherwise
+ * RAWDEV_RCCL_LIB names the file to load, otherwise librccl.so.1 from the loader path.  RD_NODE_REDUCE=standin (tests
+ * only) loads exactly the file RAWDEV_RCCL_LIB names -- tests/cpp/rccl_standin.cpp -- and accepts a device listed twice. */
 typedef struct rd_node_batch rd_node_batch;
 int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
                          uint32_t with_histogram, rd_node_batch **out);
@@ -290,6 +311,15 @@ int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_ca
                     uint32_t *height, uint32_t *components, uint32_t *precision);
 
 /* ---- plumbing for hosts without a HIP binding (tests, the Python mirror) -------------------- */
+/* Page-locked host memory (hipHostMalloc): a render destination the DMA engines write directly (see
+ * rd_render_full_res_to_bytes).  rd_host_free(device, NULL) is a no-op. */
+int rd_host_alloc(int device, size_t bytes, void **out);
+int rd_host_free(int device, void *ptr);
+/* Measurement aid (bench.py's roofline.box_*): what THIS device streams right now, with librawdev's own trivial kernels --
+ * a float4 copy of `bytes` to another buffer (GB/s counts the bytes read plus the bytes written), a non-temporal float4
+ * fill and a float4 read of `bytes`; each launched `reps` times on a private stream, the median launch reported.  Any
+ * output may be NULL.  Allocates 2 x bytes of device memory for the call. */
+int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps);
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);
 int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes);

@@ -40,13 +40,52 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+_SO_NATIVE = os.path.join(_HERE, "libdevelop_ref_native.so")
+_NATIVE_TAG = _SO_NATIVE + ".host"
+
+
+def _host_tag() -> str:
+    """Which CPU a -march=native build belongs to: model name + the flag set of the first core."""
+    model, flags = "", ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and not model:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = line.split(":", 1)[1].strip()
+                if model and flags:
+                    break
+    except OSError:
+        pass
+    import hashlib
+    return f"{model}|{hashlib.sha256(flags.encode()).hexdigest()[:16]}"
+
+
+def build_native() -> str:
+    """The -O3 -march=native flavour (bench.py's cpu_baseline), compiled on THIS machine: rebuilt whenever the
+    sources changed or the file was built for another CPU."""
+    src = [os.path.join(_HERE, f) for f in ("develop_ref.c", "develop_ref.h", "Makefile")]
+    tag = _host_tag()
+    have = ""
+    try:
+        have = open(_NATIVE_TAG).read()
+    except OSError:
+        pass
+    stale = (not os.path.exists(_SO_NATIVE)) or have != tag or any(os.path.getmtime(s) > os.path.getmtime(_SO_NATIVE) for s in src)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "-s", "native"], check=True)
+        with open(_NATIVE_TAG, "w") as f:
+            f.write(tag)
+    return _SO_NATIVE
+
+
 _lib = None
+_lib_native = None
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(build())
+def _bind(path):
+        L = C.CDLL(path)
         u16p, f32p, u8p, u32p = (C.POINTER(t) for t in (C.c_uint16, C.c_float, C.c_uint8, C.c_uint32))
         UP = C.POINTER(RefUniforms)
         L.ref_log2f.restype = C.c_float; L.ref_log2f.argtypes = [C.c_float]
@@ -68,8 +107,22 @@ def lib():
         for f in (L.ref_default_params, L.ref_derived_dims, L.ref_render_f32, L.ref_render_f32_mt,
                   L.ref_pack_u8, L.ref_pack_f16, L.ref_histogram):
             f.restype = None
-        _lib = L
+        return L
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _bind(build())
     return _lib
+
+
+def lib_native():
+    """The same oracle compiled -O3 -march=native on this machine (cpu_baseline only; the checker is lib())."""
+    global _lib_native
+    if _lib_native is None:
+        _lib_native = _bind(build_native())
+    return _lib_native
 
 
 def make_uniforms(params=None, wb=(1, 1, 1, 1), cm=(1, 0, 0, 0, 1, 0, 0, 0, 1),

@@ -9,7 +9,7 @@ import sys
 from .build import LIB_PATH
 
 RD_OK = 0
-ABI_VERSION = 2          # include/rawdev.h RD_ABI_VERSION
+ABI_VERSION = 3          # include/rawdev.h RD_ABI_VERSION
 FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8, FMT_RGB_U8 = 0, 1, 2, 3
 MATH_STRICT, MATH_CONTRACTED = 0, 1
 MATRIX_REFERENCE, MATRIX_ROW_MAJOR = 0, 1
@@ -50,6 +50,7 @@ PROTOTYPES = {
     "rd_abi_version": (_I, []),
     "rd_last_error": (C.c_char_p, []),
     "rd_device_count": (_I, [C.POINTER(_I)]),
+    "rd_device_identity": (_I, [_I, C.c_char_p, _SZ, C.c_char_p, _SZ]),
     "rd_edit_params_default": (None, [C.POINTER(RdEditParams)]),
     "rd_derived_dims": (_I, [_U32, _U32] + [C.POINTER(_U32)] * 4),
     "rd_format_bytes_per_pixel": (_SZ, [_U32]),
@@ -98,6 +99,9 @@ PROTOTYPES = {
     "rd_selftest_f16": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64)]),
     "rd_selftest_f16_halves": (_I, [_I, _U32, _U32, _VP]),
     "rd_ljpeg_decode": (_I, [_VP, _SZ, _VP, _SZ, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
+    "rd_host_alloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
+    "rd_host_free": (_I, [_I, _VP]),
+    "rd_measure_hbm": (_I, [_I, _SZ, _U32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_device_free": (_I, [_I, _VP]),
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),

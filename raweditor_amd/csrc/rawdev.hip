@@ -13,9 +13,11 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -62,6 +64,24 @@ extern "C" int rd_device_count(int *count)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; return rd_fail(RD_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
+    return RD_OK;
+}
+
+// PCI bus id ("0000:c1:00.0") and marketing name of a visible device: what tells two ranks of a multi-GPU run apart.
+extern "C" int rd_device_identity(int device, char *pci_bus_id, size_t pci_cap, char *name, size_t name_cap)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return rd_fail(RD_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return rd_fail(RD_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    if (pci_bus_id && pci_cap) {
+        pci_bus_id[0] = 0;
+        RD_HIP(hipDeviceGetPCIBusId(pci_bus_id, (int)pci_cap, device));
+    }
+    if (name && name_cap) {
+        hipDeviceProp_t prop;
+        RD_HIP(hipGetDeviceProperties(&prop, device));
+        snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
     return RD_OK;
 }
 
@@ -402,8 +422,116 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
 }
 
 // ------------------------------------------------------------------------------------------------
+// host-side copy pool: staging buffer -> caller's pageable destination on several cores
+// ------------------------------------------------------------------------------------------------
+// A render into PAGEABLE host memory (a Rust Vec<u8>, a numpy array) cannot be the target of a DMA: the surface goes
+// device -> pinned staging -> destination, and the second hop is a CPU memcpy.  One core moves ~10 GB/s (less while it
+// takes the first-touch page faults of a fresh destination), PCIe delivers ~56 GB/s, so the hop is spread over a few
+// helper threads.  Process-wide, started on first use, never joined (the object is leaked on purpose: no destructor
+// runs against waiting threads at exit).  RD_COPY_THREADS = helpers (default 4; 0 = the calling thread alone).
+namespace {
+struct rd_copy_pool {
+    struct job { char *d; const char *s; size_t n; };
+    std::mutex run_mu;                         // one parallel copy at a time
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<job> jobs;
+    size_t next = 0, pending = 0;
+    unsigned helpers = 0;
+
+    static rd_copy_pool &get()
+    {
+        static rd_copy_pool *pool = [] {
+            rd_copy_pool *p = new rd_copy_pool;
+            const char *e = getenv("RD_COPY_THREADS");
+            long want = e && *e ? strtol(e, nullptr, 10) : 4;
+            const long hw = (long)std::thread::hardware_concurrency();
+            if (hw > 0 && want > hw - 1) want = hw - 1;
+            if (want < 0) want = 0;
+            if (want > 16) want = 16;
+            for (long i = 0; i < want; ++i) {
+                try { std::thread([p] { p->work(); }).detach(); p->helpers += 1; } catch (...) { break; }
+            }
+            return p;
+        }();
+        return *pool;
+    }
+    bool take(job &j)                           // caller holds mu
+    {
+        if (next >= jobs.size()) return false;
+        j = jobs[next++];
+        return true;
+    }
+    void work()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            job j;
+            if (!take(j)) { cv_work.wait(lk); continue; }
+            lk.unlock();
+            memcpy(j.d, j.s, j.n);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    // dst[0..n) = src[0..n), split into 2 MiB-aligned pieces over the helpers and the calling thread
+    void copy(void *dst, const void *src, size_t n)
+    {
+        const size_t parts = helpers + 1u;
+        if (parts == 1u || n < (4u << 20)) { memcpy(dst, src, n); return; }
+        std::lock_guard<std::mutex> run(run_mu);
+        std::unique_lock<std::mutex> lk(mu);
+        jobs.clear(); next = 0;
+        size_t piece = ((n + parts - 1) / parts + ((2u << 20) - 1)) & ~(size_t)((2u << 20) - 1);
+        for (size_t off = 0; off < n; off += piece)
+            jobs.push_back(job{ (char *)dst + off, (const char *)src + off, n - off < piece ? n - off : piece });
+        pending = jobs.size();
+        cv_work.notify_all();
+        for (;;) {                              // the calling thread copies too
+            job j;
+            if (!take(j)) break;
+            lk.unlock();
+            memcpy(j.d, j.s, j.n);
+            lk.lock();
+            --pending;
+        }
+        cv_done.wait(lk, [this] { return pending == 0; });
+    }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
 // rd_pipeline
 // ------------------------------------------------------------------------------------------------
+// A render LANE: everything one host-side render call needs besides the CFA plane -- a compute stream, a copy stream,
+// a device surface, a 768-bin histogram, pinned staging for pageable destinations, events.  The reference shares
+// Arc<RenderPipeline> between the UI thread (render_to_bytes + render_to_histogram_bytes per redraw, main.rs:1515-1531)
+// and the export thread (render_full_res_to_bytes, main.rs:1749-1754); each call takes a free lane for its duration, so
+// the 96.6 MB read-back of an export does not stand between a slider move and its preview.  The pipeline's mutex only
+// guards the uniforms: a render snapshots them (rd_shot) and lets go.
+#define RD_LANES_MAX 4
+#define RD_BANDS_MAX 8                           // row-band launches of a full-resolution host render
+#define RD_STAGE_SLOTS 3                         // pinned staging slots of RD_STAGE_BYTES each (pageable destinations)
+#define RD_STAGE_BYTES ((size_t)8 << 20)
+#define RD_BAND_MIN_BYTES ((size_t)16 << 20)     // smaller surfaces: one launch, one copy
+
+struct rd_lane {
+    hipStream_t compute = nullptr, copy = nullptr;
+    void *out_buf = nullptr; size_t out_cap = 0;
+    uint32_t *hist_dev = nullptr;
+    void *stage[RD_STAGE_SLOTS] = {};
+    hipEvent_t kev[RD_BANDS_MAX] = {};           // band k's kernel has finished (compute stream)
+    hipEvent_t cev[RD_STAGE_SLOTS] = {};         // the copy into staging slot j has finished (copy stream)
+    hipEvent_t done = nullptr;                   // the copy stream has drained this call's chunks
+    bool busy = false;
+};
+
+struct rd_shot {                                 // what a render needs from the pipeline's mutable state
+    rd_ku u;
+    bool export_view;                            // zoom 1, pan 0: the export map may apply
+    uint32_t math_mode;
+};
+
 struct rd_pipeline {
     int device = 0;
     rd_info info{};
@@ -417,13 +545,93 @@ struct rd_pipeline {
     uint32_t black_level = 0;
     uint32_t math_mode = RD_MATH_STRICT;
     uint32_t matrix_layout = RD_MATRIX_REFERENCE;
-    // scratch
-    hipStream_t stream = nullptr;
-    void *out_buf = nullptr; size_t out_cap = 0;
-    uint32_t *hist_dev = nullptr;     // 768, for the synchronous entry points (used under mu, on `stream`)
-    rd_scratch scratch;               // per stream: ticket counters + histogram slab
-    std::mutex mu;                    // uniforms + scratch (Send + Sync like Arc<RenderPipeline>)
+    hipStream_t stream = nullptr;     // lane 0's compute stream ("the pipeline's own stream" of the test hooks)
+    rd_scratch scratch;               // per stream: ticket counters + histogram slab (has its own lock)
+    std::mutex mu;                    // the uniforms (Send + Sync like Arc<RenderPipeline>)
+    std::mutex lane_mu;               // the lane pool
+    std::condition_variable lane_cv;
+    std::vector<rd_lane *> lanes;
 };
+
+static void rd_lane_free(rd_lane *l)             // device set, nothing of the lane in flight
+{
+    if (!l) return;
+    if (l->compute) { (void)hipStreamSynchronize(l->compute); (void)hipStreamDestroy(l->compute); }
+    if (l->copy) { (void)hipStreamSynchronize(l->copy); (void)hipStreamDestroy(l->copy); }
+    if (l->out_buf) (void)hipFree(l->out_buf);
+    if (l->hist_dev) (void)hipFree(l->hist_dev);
+    for (void *s : l->stage) if (s) (void)hipHostFree(s);
+    for (hipEvent_t e : l->kev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : l->cev) if (e) (void)hipEventDestroy(e);
+    if (l->done) (void)hipEventDestroy(l->done);
+    delete l;
+}
+
+static int rd_lane_new(rd_lane **out)            // device set
+{
+    *out = nullptr;
+    rd_lane *l = new (std::nothrow) rd_lane;
+    if (!l) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    hipError_t e = hipStreamCreateWithFlags(&l->compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&l->copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->hist_dev, 768 * sizeof(uint32_t));
+    for (int k = 0; k < RD_BANDS_MAX && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&l->kev[k], hipEventDisableTiming);
+    for (int k = 0; k < RD_STAGE_SLOTS && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&l->cev[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        rd_lane_free(l);
+        return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "render lane setup failed: %s", hipGetErrorString(e));
+    }
+    *out = l;
+    return RD_OK;
+}
+
+// A free lane for a render that needs `need` bytes of device surface: the smallest free one that is large enough, else
+// any free one (it grows), else a new one (up to RD_LANES_MAX), else wait for a call to finish.
+static int rd_lane_acquire(rd_pipeline *p, size_t need, rd_lane **out)
+{
+    *out = nullptr;
+    std::unique_lock<std::mutex> lk(p->lane_mu);
+    for (;;) {
+        rd_lane *fit = nullptr, *any = nullptr;
+        for (rd_lane *l : p->lanes) {
+            if (l->busy) continue;
+            if (!any || l->out_cap > any->out_cap) any = l;
+            if (l->out_cap >= need && (!fit || l->out_cap < fit->out_cap)) fit = l;
+        }
+        rd_lane *l = fit;
+        if (!l && any && (p->lanes.size() >= RD_LANES_MAX || need <= RD_BAND_MIN_BYTES || any->out_cap == 0)) l = any;
+        if (!l && p->lanes.size() < RD_LANES_MAX) {
+            const int rc = rd_lane_new(&l);
+            if (rc) return rc;
+            p->lanes.push_back(l);
+        }
+        if (!l && any) l = any;
+        if (l) { l->busy = true; *out = l; return RD_OK; }
+        p->lane_cv.wait(lk);
+    }
+}
+
+static void rd_lane_release(rd_pipeline *p, rd_lane *l)
+{
+    { std::lock_guard<std::mutex> lk(p->lane_mu); l->busy = false; }
+    p->lane_cv.notify_one();
+}
+
+struct rd_lane_hold {                            // RAII: a lane for the duration of one call
+    rd_pipeline *p; rd_lane *l = nullptr; int rc;
+    rd_lane_hold(rd_pipeline *pp, size_t need) : p(pp) { rc = rd_lane_acquire(pp, need, &l); }
+    ~rd_lane_hold() { if (l) rd_lane_release(p, l); }
+};
+
+static int rd_lane_reserve(rd_lane *l, size_t need)          // the lane's device surface holds `need` bytes
+{
+    if (l->out_cap >= need) return RD_OK;
+    if (l->out_buf) { (void)hipFree(l->out_buf); l->out_buf = nullptr; l->out_cap = 0; }
+    RD_HIP(hipMalloc(&l->out_buf, need));
+    l->out_cap = need;
+    return RD_OK;
+}
 
 static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bool cfa_on_device,
                            uint32_t w, uint32_t h, const rd_edit_params *params, const float wb[4],
@@ -453,18 +661,20 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
     memcpy(p->cm, cm, sizeof p->cm);
     p->identity_ok = rd_identity_map(w) && rd_identity_map(h);
 
-    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->hist_dev, 768 * sizeof(uint32_t));
-    if (e == hipSuccess) {
-        if (cfa_on_device) {
-            p->cfa = cfa;
-        } else {
-            void *d = nullptr;
-            e = hipMalloc(&d, (size_t)w * h * sizeof(uint16_t));
-            if (e == hipSuccess) {
-                p->cfa = (const uint16_t *)d; p->owns_cfa = true;
-                e = hipMemcpy(d, cfa, (size_t)w * h * sizeof(uint16_t), hipMemcpyHostToDevice);
-            }
+    rd_lane *l0 = nullptr;
+    rc = rd_lane_new(&l0);
+    if (rc) { rd_pipeline_destroy(p); return rc; }
+    p->lanes.push_back(l0);
+    p->stream = l0->compute;
+    hipError_t e = hipSuccess;
+    if (cfa_on_device) {
+        p->cfa = cfa;
+    } else {
+        void *d = nullptr;
+        e = hipMalloc(&d, (size_t)w * h * sizeof(uint16_t));
+        if (e == hipSuccess) {
+            p->cfa = (const uint16_t *)d; p->owns_cfa = true;
+            e = hipMemcpy(d, cfa, (size_t)w * h * sizeof(uint16_t), hipMemcpyHostToDevice);
         }
     }
     if (e != hipSuccess) {
@@ -495,10 +705,9 @@ extern "C" void rd_pipeline_destroy(rd_pipeline *p)
     if (!p) return;
     {
         rd_devguard g(p->device);
-        if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+        for (rd_lane *l : p->lanes) rd_lane_free(l);
+        p->lanes.clear();
         if (p->owns_cfa && p->cfa) (void)hipFree((void *)p->cfa);
-        if (p->out_buf) (void)hipFree(p->out_buf);
-        if (p->hist_dev) (void)hipFree(p->hist_dev);
         (void)hipDeviceSynchronize();        // renders enqueued on caller streams (rd_render_device) may still draw tickets
         p->scratch.release();
     }
@@ -553,23 +762,43 @@ extern "C" int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params)
     return rd_update_uniforms_with_zoom(p, params, 1.0f, 0.0f, 0.0f);   // pipeline.rs:367-369
 }
 
-// caller holds p->mu and has the device set
-static int rd_pipeline_enqueue(rd_pipeline *p, uint32_t tw, uint32_t th, uint32_t fmt, void *dst_dev,
-                               uint32_t *hist_dev, hipStream_t s)
+// The uniforms as they stand now: the only thing a render reads under the pipeline's mutex.  (The reference's export
+// re-uses whatever view() last wrote, main.rs:1515 vs :1754; a snapshot keeps that and removes the tear a concurrent
+// queue.write_buffer can cause there.)
+static rd_shot rd_pipeline_snapshot(rd_pipeline *p)
+{
+    std::lock_guard<std::mutex> lk(p->mu);
+    rd_shot s;
+    s.u = rd_frame_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode, p->matrix_layout);
+    s.export_view = p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f;
+    s.math_mode = p->math_mode;
+    return s;
+}
+
+// Does a tw x th render of this snapshot take the export kernel (one 2x2 block per lane, identity map)?
+static bool rd_pipeline_uses_quads(const rd_pipeline *p, const rd_shot &sh, uint32_t tw, uint32_t th, uint32_t fmt)
+{
+    const uint32_t W = p->info.width, H = p->info.height;
+    return tw == W && th == H && sh.export_view && (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
+           (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
+}
+
+// Enqueue one render of the snapshot on stream s: units [unit0, unit1) of the export kernel (the whole frame is
+// [0, H/2 + 1)), or the map kernel for any other target.  The device is set.  With hist_dev the launch must be the whole frame.
+static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, uint32_t th, uint32_t fmt, void *dst_dev,
+                               uint32_t *hist_dev, hipStream_t s, uint32_t unit0 = 0, uint32_t unit1 = 0)
 {
     if (!tw || !th) return rd_fail(RD_ERR_INVALID_ARG, "empty target %ux%u", tw, th);
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
     if ((uintptr_t)dst_dev % rd_align_for(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "dst is not %zu-byte aligned", rd_align_for(fmt));
     const uint32_t W = p->info.width, H = p->info.height;
-    const rd_ku u = rd_frame_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode, p->matrix_layout);
-    const bool quads = tw == W && th == H && p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f &&
-                       (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
-                       (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
+    const bool quads = rd_pipeline_uses_quads(p, sh, tw, th, fmt);
+    if (!unit1) unit1 = H / 2u + 1u;
     uint32_t blocks = 0;
     const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, u, quads, 0, H / 2u + 1u,
-                               hist_dev != nullptr, p->math_mode, l.slab32, nullptr, 0, l.tq, s, &blocks);
+    int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, sh.u, quads, unit0, unit1,
+                               hist_dev != nullptr, sh.math_mode, l.slab32, nullptr, 0, l.tq, s, &blocks);
     if (rc == RD_OK && hist_dev) {
         hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, s, l.slab32, blocks, hist_dev);
         const hipError_t e = hipGetLastError();
@@ -585,8 +814,104 @@ extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, 
     if (!p || !dst_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     rd_devguard g(p->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    std::lock_guard<std::mutex> lk(p->mu);   // the slab is shared scratch
-    return rd_pipeline_enqueue(p, out_w, out_h, fmt, dst_dev, hist_dev, (hipStream_t)stream);
+    const rd_shot sh = rd_pipeline_snapshot(p);
+    return rd_pipeline_enqueue(p, sh, out_w, out_h, fmt, dst_dev, hist_dev, (hipStream_t)stream);
+}
+
+// Is [ptr, ptr + n) page-locked host memory the DMA engines can write (hipHostMalloc / rd_host_alloc / hipHostRegister)?
+static bool rd_is_pinned_host(const void *ptr, size_t n)
+{
+    if (getenv("RD_ASSUME_PAGEABLE")) return false;          // A/B switch: stage every destination
+    const char *ends[2] = { (const char *)ptr, (const char *)ptr + (n ? n - 1 : 0) };
+    for (const char *q : ends) {
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof a);
+        const hipError_t e = hipPointerGetAttributes(&a, q);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }      // plain malloc memory: "invalid value"
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+// Full-resolution host render (render_full_res_to_bytes, pipeline.rs:526-606, and rd_render of the whole frame): the
+// reference renders, copies the texture into a MAP_READ buffer, blocks in poll(Wait) and de-pads 96.6 MB row by row
+// ("1-2 seconds for 24MP", pipeline.rs:525).  Here, on the lane's two streams:
+//   * the frame is launched as up to RD_BANDS_MAX row bands (the export kernel takes a unit range; a band's rows are
+//     contiguous bytes of the surface), so the first bytes cross PCIe while the later bands are still being computed;
+//   * a page-locked destination (rd_host_alloc / hipHostMalloc / hipHostRegister; detected) is written by the DMA
+//     engine directly, in chunks, all enqueued at once: one synchronise, no host copy;
+//   * a pageable destination goes through RD_STAGE_SLOTS pinned slots of 8 MiB: the DMA of chunk c+3 runs while the
+//     copy pool moves chunk c into the caller's buffer.
+// With a fused histogram the slab is written by ONE launch (no bands); the copies are chunked all the same.
+static int rd_render_full_host(rd_pipeline *p, rd_lane *l, const rd_shot &sh, uint32_t fmt, char *dst, size_t need, uint32_t *hist)
+{
+    const uint32_t W = p->info.width, H = p->info.height;
+    const size_t row_bytes = (size_t)W * rd_format_bytes_per_pixel(fmt);
+    const uint32_t units = H / 2u + 1u;
+    static const uint32_t bands_env = rd_env_u32("RD_RENDER_BANDS", RD_BANDS_MAX);
+    uint32_t bands = hist ? 1u : (bands_env < RD_BANDS_MAX ? bands_env : RD_BANDS_MAX);
+    if (bands > units) bands = units;
+    if (!bands) bands = 1u;
+    size_t band_end[RD_BANDS_MAX];                           // bytes of the surface complete after band k
+    int rc = RD_OK;
+    for (uint32_t k = 0; k < bands && rc == RD_OK; ++k) {
+        const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands), u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
+        const uint32_t row_hi = 2u * (u1 - 1u) < H ? 2u * (u1 - 1u) + 1u : H;      // exclusive: the last unit's row b
+        band_end[k] = k + 1u == bands ? need : (size_t)row_hi * row_bytes;
+        rc = rd_pipeline_enqueue(p, sh, W, H, fmt, l->out_buf, hist ? l->hist_dev : nullptr, l->compute, u0, u1);
+        if (rc == RD_OK) RD_HIP(hipEventRecord(l->kev[k], l->compute));
+    }
+    if (rc) return rc;
+    const bool pinned = rd_is_pinned_host(dst, need);
+    static const size_t chunk_pinned = (size_t)rd_env_u32("RD_COPY_CHUNK_MB", 16) << 20;
+    const size_t chunk = pinned ? chunk_pinned : RD_STAGE_BYTES;
+    const size_t nchunks = (need + chunk - 1) / chunk;
+    uint32_t waited = 0;                                     // bands [0, waited) are already ordered before the copy stream's tail
+    auto enqueue_chunk = [&](size_t c, void *to) -> hipError_t {
+        const size_t off = c * chunk, len = need - off < chunk ? need - off : chunk;
+        hipError_t e = hipSuccess;
+        while (e == hipSuccess && waited < bands && (waited == 0 || band_end[waited - 1u] < off + len))
+            e = hipStreamWaitEvent(l->copy, l->kev[waited++], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(to, (const char *)l->out_buf + off, len, hipMemcpyDeviceToHost, l->copy);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    if (pinned) {
+        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) e = enqueue_chunk(c, dst + c * chunk);
+        if (e == hipSuccess && hist) {
+            e = hipStreamWaitEvent(l->copy, l->kev[0], 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->copy);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(l->copy);
+    } else {
+        for (int j = 0; j < RD_STAGE_SLOTS && e == hipSuccess; ++j)
+            if (!l->stage[j]) e = hipHostMalloc(&l->stage[j], RD_STAGE_BYTES, hipHostMallocDefault);
+        for (size_t c = 0; c < nchunks && c < RD_STAGE_SLOTS && e == hipSuccess; ++c) {
+            e = enqueue_chunk(c, l->stage[c]);
+            if (e == hipSuccess) e = hipEventRecord(l->cev[c], l->copy);
+        }
+        rd_copy_pool &pool = rd_copy_pool::get();
+        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+            const size_t j = c % RD_STAGE_SLOTS, off = c * chunk, len = need - off < chunk ? need - off : chunk;
+            e = hipEventSynchronize(l->cev[j]);
+            if (e != hipSuccess) break;
+            pool.copy(dst + off, l->stage[j], len);
+            if (c + RD_STAGE_SLOTS < nchunks) {              // the slot is free again: the chunk three ahead goes into it
+                e = enqueue_chunk(c + RD_STAGE_SLOTS, l->stage[j]);
+                if (e == hipSuccess) e = hipEventRecord(l->cev[j], l->copy);
+            }
+        }
+        if (e == hipSuccess && hist) {
+            e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->compute);
+            if (e == hipSuccess) e = hipStreamSynchronize(l->compute);
+        }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(l->copy); (void)hipStreamSynchronize(l->compute); }
+    }
+    if (e != hipSuccess) {                                    // whatever ran may have stopped half way: counters are suspect
+        p->scratch.mark_all_dirty();
+        return rd_fail(RD_ERR_HIP, "render readback failed: %s", hipGetErrorString(e));
+    }
+    return RD_OK;
 }
 
 extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst, size_t dst_len,
@@ -600,17 +925,19 @@ extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_
     if (dst_len != need) return rd_fail(RD_ERR_INVALID_ARG, "dst_len %zu != %ux%ux%zu = %zu", dst_len, out_w, out_h, bpp, need);
     rd_devguard g(p->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (p->out_cap < need) {
-        if (p->out_buf) { (void)hipFree(p->out_buf); p->out_buf = nullptr; p->out_cap = 0; }
-        RD_HIP(hipMalloc(&p->out_buf, need));
-        p->out_cap = need;
-    }
-    int rc = rd_pipeline_enqueue(p, out_w, out_h, fmt, p->out_buf, hist ? p->hist_dev : nullptr, p->stream);
+    const rd_shot sh = rd_pipeline_snapshot(p);               // the pipeline's mutex is held for this line only
+    rd_lane_hold hold(p, need);
+    rd_lane *l = hold.l;
+    if (!l) return hold.rc;
+    int rc = rd_lane_reserve(l, need);
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dst, p->out_buf, need, hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess && hist) e = hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (need >= RD_BAND_MIN_BYTES && rd_pipeline_uses_quads(p, sh, out_w, out_h, fmt))
+        return rd_render_full_host(p, l, sh, fmt, (char *)dst, need, hist);
+    rc = rd_pipeline_enqueue(p, sh, out_w, out_h, fmt, l->out_buf, hist ? l->hist_dev : nullptr, l->compute);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dst, l->out_buf, need, hipMemcpyDeviceToHost, l->compute);
+    if (e == hipSuccess && hist) e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(l->compute);
     if (e != hipSuccess) {                                    // whatever ran may have stopped half way: counters are suspect
         p->scratch.mark_all_dirty();
         return rd_fail(RD_ERR_HIP, "render readback failed: %s", hipGetErrorString(e));
@@ -645,24 +972,44 @@ extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_
     if (!npx) { memset(hist, 0, 768 * sizeof(uint32_t)); return RD_OK; }
     rd_devguard g(p->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (p->out_cap < rgba_len) {
-        if (p->out_buf) { (void)hipFree(p->out_buf); p->out_buf = nullptr; p->out_cap = 0; }
-        RD_HIP(hipMalloc(&p->out_buf, rgba_len));
-        p->out_cap = rgba_len;
-    }
-    RD_HIP(hipMemcpyAsync(p->out_buf, rgba, rgba_len, hipMemcpyHostToDevice, p->stream));
+    rd_lane_hold hold(p, rgba_len);
+    rd_lane *ln = hold.l;
+    if (!ln) return hold.rc;
+    int rc = rd_lane_reserve(ln, rgba_len);
+    if (rc) return rc;
+    RD_HIP(hipMemcpyAsync(ln->out_buf, rgba, rgba_len, hipMemcpyHostToDevice, ln->compute));
     const uint32_t blocks = rd_blocks_for(p->cfg, npx, true);
-    const rd_scratch::lease l = p->scratch.get(p->stream, true);
+    const rd_scratch::lease l = p->scratch.get(ln->compute, true);
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, p->stream, (const uint32_t *)p->out_buf,
+    hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, ln->compute, (const uint32_t *)ln->out_buf,
                        (uint32_t)npx, l.slab32);
-    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, p->stream, l.slab32, blocks, p->hist_dev);
+    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, ln->compute, l.slab32, blocks, ln->hist_dev);
     const hipError_t le = hipGetLastError();
-    p->scratch.used(l, p->stream, le != hipSuccess);
+    p->scratch.used(l, ln->compute, le != hipSuccess);
     RD_HIP(le);
-    RD_HIP(hipMemcpyAsync(hist, p->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
-    RD_HIP(hipStreamSynchronize(p->stream));
+    RD_HIP(hipMemcpyAsync(hist, ln->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, ln->compute));
+    RD_HIP(hipStreamSynchronize(ln->compute));
+    return RD_OK;
+}
+
+// Page-locked host memory for render destinations (and sources): what a host that wants the direct-DMA path allocates
+// its surface buffer from.  Any thread, any time; rd_host_free(NULL) is a no-op.
+extern "C" int rd_host_alloc(int device, size_t bytes, void **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RD_OK;
+}
+
+extern "C" int rd_host_free(int device, void *ptr)
+{
+    if (!ptr) return RD_OK;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    RD_HIP(hipHostFree(ptr));
     return RD_OK;
 }
 
@@ -1002,7 +1349,7 @@ struct rd_rccl_api {
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
     bool ok = false;
-    bool standin = false;                        // the test stand-in, not RCCL: ranks may then share a device
+    bool standin = false;                        // RD_NODE_REDUCE=standin: the tests' stand-in, not RCCL (ranks may share a device)
 };
 constexpr int RD_NCCL_UINT64 = 5, RD_NCCL_SUM = 0;           // rccl.h: ncclUint64, ncclSum
 
@@ -1012,15 +1359,24 @@ rd_rccl_api &rd_rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char *env = getenv("RAWDEV_RCCL_LIB");
+        const char *mode = getenv("RD_NODE_REDUCE");
         const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        // an explicitly named library wins (RAWDEV_RCCL_LIB); otherwise a copy that is already mapped (a PyTorch process
-        // has its own) serves us too: one RCCL per process
-        if (env && *env) {
+        // One RCCL per process: a copy that is already mapped (a PyTorch process has its own) serves us too and wins over
+        // RAWDEV_RCCL_LIB, which only names the file to load when none is.  The exception is explicit:
+        // RD_NODE_REDUCE=standin (tests) loads exactly the file RAWDEV_RCCL_LIB names -- the host-memory stand-in of
+        // tests/cpp/rccl_standin.cpp -- and only then may ranks share a device.
+        if (mode && !strcmp(mode, "standin")) {
+            if (!env || !*env) { api.error = "RD_NODE_REDUCE=standin needs RAWDEV_RCCL_LIB=<the stand-in library>"; return; }
             api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
             if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
+            api.standin = true;
         }
         for (const char *n : { "librccl.so.1", "librccl.so" })
             if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (!api.handle && env && *env) {
+            api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
+        }
         for (const char *n : names)
             if (!api.handle && n && *n) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!api.handle) { api.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return; }
@@ -1032,8 +1388,6 @@ rd_rccl_api &rd_rccl()
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
         api.ok = api.error.empty();
-        // tests/cpp/rccl_standin.cpp (a host-memory all-reduce for one-GPU rehearsals of the grouped call sequence) says so
-        api.standin = api.ok && dlsym(api.handle, "rawdev_rccl_standin") != nullptr;
     });
     return api;
 }
@@ -1088,11 +1442,13 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
     bool dup = false;
     for (uint32_t a = 0; a < n_devices; ++a)
         for (uint32_t b = a + 1; b < n_devices; ++b) dup = dup || devices[a] == devices[b];
-    const char *env = getenv("RD_NODE_REDUCE");              // "host": fold on the host; "rccl": a communicator even for N = 1
-    const bool want_host = env && !strcmp(env, "host"), want_rccl = env && !strcmp(env, "rccl");
-    // A device listed twice is a rehearsal of N > 1 on a one-GPU box: allowed with the host fold, or when RAWDEV_RCCL_LIB
-    // names the test stand-in (real RCCL wants one rank per device).
-    if (dup && !want_host && !(getenv("RAWDEV_RCCL_LIB") && rd_rccl().standin))
+    const char *env = getenv("RD_NODE_REDUCE");              // "host": fold on the host; "rccl": a communicator even for N = 1;
+    const bool want_host = env && !strcmp(env, "host");      // "standin": the RCCL branch over the tests' stand-in library
+    const bool want_standin = env && !strcmp(env, "standin");
+    const bool want_rccl = want_standin || (env && !strcmp(env, "rccl"));
+    // A device listed twice is a rehearsal of N > 1 on a one-GPU box: allowed only on explicit request -- the host fold, or
+    // the stand-in for librccl (real RCCL wants one rank per device).
+    if (dup && !want_host && !want_standin)
         return rd_fail(RD_ERR_INVALID_ARG, "device list holds a device twice (RCCL wants one rank per device; RD_NODE_REDUCE=host "
                                            "allows it for rehearsals on a one-GPU box)");
     rd_node_batch *nb = new (std::nothrow) rd_node_batch;
@@ -1519,6 +1875,88 @@ extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, si
     case rd_ljpeg::ERR_TRUNCATED: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: lossless-JPEG stream is truncated");
     default: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: malformed lossless-JPEG stream");
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement aid: the streaming ceilings of THIS device, now (bench.py: roofline.box_copy_GBps / box_fill_GBps)
+// ------------------------------------------------------------------------------------------------
+// Boxes of one pool differ by a few per cent (power-managed clocks), and SURVEY.md section 8d asks for the roofline
+// fraction against a ceiling measured on the box, not only against the 8 TB/s of the data sheet.  Three trivial
+// persistent kernels, 16 B per lane and access, 2048 workgroups x 256 threads: copy (plain loads, nt stores), fill (nt
+// stores), read (loads folded into a value nobody needs).
+__global__ void __launch_bounds__(256) rd_probe_copy(const rd_f4 *__restrict__ src, rd_f4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(src[i], dst + i);
+}
+
+__global__ void __launch_bounds__(256) rd_probe_fill(rd_f4 *__restrict__ dst, size_t n, float v)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    const rd_f4 x = { v, v + 1.0f, v + 2.0f, 1.0f };
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(x, dst + i);
+}
+
+__global__ void __launch_bounds__(256) rd_probe_read(const rd_f4 *__restrict__ src, size_t n, float *sink)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) { const rd_f4 v = src[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 12345.678f) *sink = acc;                      // never true for the zeroed buffer: keeps the loads alive
+}
+
+extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps)
+{
+    if (bytes < (1u << 20) || !reps || reps > 64) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need >= 1 MiB and 1..64 repetitions");
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    const size_t n = bytes / sizeof(rd_f4);
+    void *a = nullptr, *b = nullptr;
+    float *sink = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a, n * sizeof(rd_f4));
+    if (e == hipSuccess) e = hipMalloc(&b, n * sizeof(rd_f4));
+    if (e == hipSuccess) e = hipMalloc((void **)&sink, sizeof(float));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * sizeof(rd_f4), s);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(rd_f4), s);
+    double out[3] = { 0.0, 0.0, 0.0 };
+    for (int which = 0; which < 3 && e == hipSuccess; ++which) {
+        std::vector<float> ms;
+        for (uint32_t r = 0; r < reps + 1u && e == hipSuccess; ++r) {             // the first launch warms up
+            e = hipEventRecord(e0, s);
+            if (which == 0) hipLaunchKernelGGL(rd_probe_copy, dim3(2048), dim3(256), 0, s, (const rd_f4 *)a, (rd_f4 *)b, n);
+            else if (which == 1) hipLaunchKernelGGL(rd_probe_fill, dim3(2048), dim3(256), 0, s, (rd_f4 *)b, n, (float)r);
+            else hipLaunchKernelGGL(rd_probe_read, dim3(2048), dim3(256), 0, s, (const rd_f4 *)a, n, sink);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(e1, s);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float t = 0.0f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+            if (e == hipSuccess && r) ms.push_back(t);
+        }
+        if (e == hipSuccess) {
+            std::sort(ms.begin(), ms.end());
+            const double med = ms[ms.size() / 2];
+            out[which] = (which == 0 ? 2.0 : 1.0) * (double)(n * sizeof(rd_f4)) / (med * 1e-3) / 1e9;
+        }
+    }
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "rd_measure_hbm: %s", hipGetErrorString(e));
+    if (copy_GBps) *copy_GBps = out[0];
+    if (fill_GBps) *fill_GBps = out[1];
+    if (read_GBps) *read_GBps = out[2];
+    return RD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

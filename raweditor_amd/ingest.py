@@ -189,7 +189,11 @@ def ljpeg_decode(stream: bytes, max_samples: Optional[int] = None) -> np.ndarray
     buf = bytes(stream)
     if len(buf) < 12 or buf[:2] != b"\xff\xd8":
         raise _decode_error("not a JPEG stream")
-    limit = LJPEG_MAX_SAMPLES if max_samples is None else int(max_samples)
+    # the module ceiling always holds; a caller's limit can only tighten it.  And the stream bounds itself: a Huffman-coded
+    # sample costs at least one bit, so no stream of len(buf) bytes holds more than 8 * len(buf) samples.
+    limit = min(LJPEG_MAX_SAMPLES, 8 * len(buf))
+    if max_samples is not None:
+        limit = min(limit, int(max_samples))
     dims = [C.c_uint32() for _ in range(4)]
     src = (C.c_uint8 * len(buf)).from_buffer_copy(buf)
     L = _lib.lib()
@@ -199,7 +203,7 @@ def ljpeg_decode(stream: bytes, max_samples: Optional[int] = None) -> np.ndarray
         raise ValueError(L.rd_last_error().decode("utf-8", "replace") if rc != 0 else "Failed to decode RAW: empty frame")
     if n > limit:
         raise _decode_error(f"lossless-JPEG frame declares {dims[0].value}x{dims[1].value}x{dims[2].value} samples, "
-                            f"more than the {limit} its tile / strip can hold")
+                            f"more than the {limit} its tile / strip / {len(buf)}-byte stream can hold")
     out = np.empty(n, np.uint16)
     rc = L.rd_ljpeg_decode(src, len(buf), out.ctypes.data_as(C.c_void_p), n, *[C.byref(d) for d in dims])
     if rc != 0:
@@ -312,6 +316,10 @@ def _read_ljpeg_image(buf: bytes, raw: dict):
     across, down = (w + tw - 1) // tw, (h + th - 1) // th
     if len(offs) != len(sizes) or len(offs) < across * down:
         raise _decode_error(f"{len(offs)} tiles / strips for a {across}x{down} grid")
+    # a Huffman-coded sample costs at least one bit: the strips / tiles of this file cannot hold more samples than 8 x
+    # their bytes, whatever the header claims -- checked before the image is allocated
+    if w * h > 8 * sum(int(x) for x in sizes[:across * down]):
+        raise _decode_error(f"{w}x{h} image cannot come out of {sum(int(x) for x in sizes[:across * down])} bytes of lossless JPEG")
     out = np.zeros((h, w), np.uint16)
     for k in range(across * down):
         o, nbytes = int(offs[k]), int(sizes[k])

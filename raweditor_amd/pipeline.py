@@ -54,6 +54,38 @@ def elided_steps(params: EditParams, wb_multipliers: Sequence[float], color_matr
     return int(_lib.lib().rd_elided_steps(C.byref(cp), wb, cm, int(math_mode)))
 
 
+class PinnedBytes:
+    """Page-locked host memory (rd_host_alloc): a render destination the DMA engines write directly -- what a host
+    hands to render_full_res_to_bytes(out=...) to skip the staging copy.  `.array` is a uint8 view; free() (or the
+    destructor) returns the memory, after which the view must not be used."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = C.c_void_p()
+        check(_lib.lib().rd_host_alloc(self.device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.ptr), dtype=np.uint8)
+
+    def free(self) -> None:
+        if getattr(self, "ptr", 0):
+            self.array = None
+            check(_lib.lib().rd_host_free(self.device, C.c_void_p(self.ptr)))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def measure_hbm(device: int = 0, nbytes: int = 1 << 30, reps: int = 5):
+    """(copy, fill, read) GB/s of this device right now with librawdev's own streaming kernels (rd_measure_hbm)."""
+    v = [C.c_double() for _ in range(3)]
+    check(_lib.lib().rd_measure_hbm(int(device), int(nbytes), int(reps), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
 class RenderPipeline:
     """Owns one CFA plane in HBM plus the current uniforms (EditParams, wb, matrix, zoom/pan)."""
 
@@ -127,16 +159,21 @@ class RenderPipeline:
         check(_lib.lib().rd_pipeline_set_math_mode(self._h, int(math_mode)))
 
     # -- renders ----------------------------------------------------------------------------------
-    def _bytes(self, fn, w: int, h: int) -> np.ndarray:
-        out = np.empty(w * h * 4, np.uint8)
+    def _bytes(self, fn, w: int, h: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if out is None:
+            out = np.empty(w * h * 4, np.uint8)           # the analogue of the reference's fresh Vec<u8>
+        elif out.dtype != np.uint8 or not out.flags.c_contiguous or out.size != w * h * 4:
+            raise RawdevError(-1, f"out must be a contiguous uint8 array of {w * h * 4} bytes")
         check(fn(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
     def render_to_bytes(self) -> np.ndarray:                                      # pipeline.rs:442-522
         return self._bytes(_lib.lib().rd_render_to_bytes, self.preview_width, self.preview_height)
 
-    def render_full_res_to_bytes(self) -> np.ndarray:                             # pipeline.rs:526-606
-        return self._bytes(_lib.lib().rd_render_full_res_to_bytes, self.width, self.height)
+    def render_full_res_to_bytes(self, out: Optional[np.ndarray] = None) -> np.ndarray:   # pipeline.rs:526-606
+        """`out` (optional): the destination to fill instead of a fresh array -- a PinnedBytes(...).array takes the
+        direct-DMA path, any other array the staged one (rd_render_full_res_to_bytes in include/rawdev.h)."""
+        return self._bytes(_lib.lib().rd_render_full_res_to_bytes, self.width, self.height, out)
 
     def render_to_histogram_bytes(self) -> np.ndarray:                            # pipeline.rs:615-716
         return self._bytes(_lib.lib().rd_render_to_histogram_bytes, self.histogram_width, self.histogram_height)

@@ -1,7 +1,7 @@
 """Run by tests/test_gpu_node_batch.py in a FRESH process (librawdev binds its RCCL library once per process):
 the RCCL branch of rd_node_batch_* with n > 1 ranks on a one-GPU box, through tests/cpp/librccl_standin.so.
 
-Environment set by the caller: RAWDEV_RCCL_LIB=<the stand-in>, RD_NODE_REDUCE unset.  Checks, for N = 2 and 4 with device 0
+Environment set by the caller: RAWDEV_RCCL_LIB=<the stand-in>, RD_NODE_REDUCE=standin (the explicit opt-in).  Checks, for N = 2 and 4 with device 0
 listed N times: the communicator path is taken (reduce kind "rccl all-reduce"), the global histogram equals the oracle's
 sum, EVERY rank's device buffer holds that sum after the grouped in-place all-reduce, surfaces are bit-identical to the
 oracle, and the stand-in saw exactly N all-reduce calls per histogram() inside ONE group.  This executes librawdev's call
@@ -45,7 +45,7 @@ def main():
             e = refc.render_f32(c, u)
             exp.append(e)
             exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
-        nb = ra.NodeBatch([0] * n_dev, w, h, fmt, True)          # device 0 listed N times: accepted only with the stand-in
+        nb = ra.NodeBatch([0] * n_dev, w, h, fmt, True)          # device 0 listed N times: accepted only with RD_NODE_REDUCE=standin
         assert nb.reduce_kind() == "rccl all-reduce", nb.reduce_kind()
         bpp = ra.BYTES_PER_PIXEL[fmt]
         d_in = [DevBuf.from_array(c) for c in cfas]

@@ -105,3 +105,75 @@ def test_main_routes_a_bare_multi_gpu_call_into_the_launcher(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "4")
     bench.main()
     assert seen == {"ranks": True}
+
+
+# ---- the N > 1 line describes itself ---------------------------------------------------------
+def _records(bus_ids, mpps=None):
+    recs = []
+    for r, bus in enumerate(bus_ids):
+        rec = bench.rank_record(r, r, r, {"pci_bus_id": bus, "name": "AMD Instinct MI355X (gfx950)"}, 2.0 + 0.01 * r, 1990.0, 20, 256,
+                                6016, 4016, 32, {"copy": 5100.0, "fill": 6200.0})
+        if mpps:
+            rec["MP_per_s"] = mpps[r]
+        recs.append(rec)
+    return recs
+
+
+def test_rank_record_holds_the_ranks_own_clocks():
+    rec = _records(["0000:05:00.0"])[0]
+    assert rec["rank"] == 0 and rec["device_index"] == 0 and rec["pci_bus_id"] == "0000:05:00.0"
+    assert rec["ms_per_step"] == 100.0 and rec["ms_per_step_hip_events"] == 99.5            # 2.0 s wall / 1990 ms of HIP events over 20 steps
+    assert rec["launches"] == 32 * 20 and abs(rec["us_per_frame"] - 1990e3 / (20 * 256)) < 1e-3
+    assert abs(rec["MP_per_s"] - 256 * 6016 * 4016 / 1e3 / 100.0) < 0.1
+    assert rec["box_copy_GBps"] == 5100.0 and rec["pid"] > 0 and rec["host"]
+
+
+def test_summarize_ranks_counts_devices_and_refuses_shared_ones_under_nccl():
+    eight = [f"0000:{i:02x}:00.0" for i in range(8)]
+    d, err = bench.summarize_ranks(list(reversed(_records(eight, mpps=[300.0 + i for i in range(8)]))), 8, 8, "nccl")
+    assert err is None and d["distinct_devices"] == 8 and d["world_size_seen"] == 8
+    assert [r["rank"] for r in d["ranks"]] == list(range(8))                             # sorted by rank, whatever the gather order
+    assert (d["per_gpu_MPps_min"], d["per_gpu_MPps_max"]) == (300.0, 307.0) and 0 < d["per_gpu_MPps_spread"] < 0.03
+    assert set(d["env"]) >= {"HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "NCCL_DEBUG"}
+    shared = eight[:7] + [eight[0]]
+    d, err = bench.summarize_ranks(_records(shared), 8, 8, "nccl")
+    assert d["distinct_devices"] == 7 and err and "7 distinct device" in err and "0000:00:00.0" in err
+    d, err = bench.summarize_ranks(_records(shared), 8, 8, "gloo")                       # the one-GPU rehearsal may share
+    assert err is None and d["distinct_devices"] == 7
+    d, err = bench.summarize_ranks(_records(eight[:4]), 8, 4, "nccl")                    # the group is smaller than the launcher said
+    assert err and "world size mismatch" in err
+    d, err = bench.summarize_ranks(_records([None, None]), 2, 2, "nccl")                 # no bus ids: fall back to the device index
+    assert err is None and d["distinct_devices"] == 2
+
+
+def _gather_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = bench.rank_record(rank, rank, 0, {"pci_bus_id": "0000:c1:00.0", "name": "one shared GPU"}, 1.0 + rank, 900.0, 10, 8,
+                                 640, 480, 1, {"copy": 1.0, "fill": 2.0})
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, mine)                    # what run_ranks does after the timed region
+        if rank == 0:
+            for rule in ("gloo", "nccl"):
+                d, err = bench.summarize_ranks(got, world, dist.get_world_size(), rule)
+                with open(os.path.join(out_dir, f"diag_{rule}.json"), "w") as f:
+                    json.dump({"diag": d, "err": err}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_records_gather_over_gloo_world_size_2(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = json.load(open(tmp_path / "diag_gloo.json"))
+    assert g["err"] is None and [r["rank"] for r in g["diag"]["ranks"]] == [0, 1]
+    assert g["diag"]["ranks"][1]["ms_per_step"] == 200.0 and g["diag"]["distinct_devices"] == 1
+    assert len({r["pid"] for r in g["diag"]["ranks"]}) == 2                                # two processes really reported
+    n = json.load(open(tmp_path / "diag_nccl.json"))
+    assert n["err"] and "under nccl every rank must own its GPU" in n["err"]

@@ -18,12 +18,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(argv, extra_env, timeout=900):
+def _bench_raw(argv, extra_env, timeout=900):
     env = dict(os.environ, **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
-                         timeout=timeout, env=env, cwd=ROOT)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+def _bench(argv, extra_env, timeout=900):
+    out = _bench_raw(argv, extra_env, timeout)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -38,6 +42,27 @@ def test_bare_multi_gpu_call_launches_its_own_ranks(gpu_lib):
     assert r["value"] > 0 and r["roofline"]["frac"] > 0
     assert "extra_configs" not in r and "cpu_baseline" not in r      # N = 1 only
     assert r["allreduce_us"]["median"] > 0 and r["allreduce_us"]["bytes"] == 6144     # reported separately
+    # the line says by itself what ran where
+    assert r["world_size_seen"] == r["world_size_env"] == 2 and r["backend"] == "gloo"
+    assert [x["rank"] for x in r["ranks"]] == [0, 1]
+    for x in r["ranks"]:
+        assert x["pci_bus_id"] and x["name"] and x["pid"] > 0
+        assert x["ms_per_step"] > 0 and x["ms_per_step_hip_events"] > 0 and x["launches"] > 0 and x["us_per_frame"] > 0 and x["MP_per_s"] > 0
+        assert x["box_copy_GBps"] > 1000 and x["box_fill_GBps"] > 1000
+    assert r["distinct_devices"] == 1                      # the rehearsal: both ranks share device 0 (allowed under gloo only)
+    assert 0 < r["per_gpu_MPps_min"] <= r["per_gpu_MPps_max"]
+    assert r["env"]["RAWDEV_DIST_BACKEND"] == "gloo" and "HSA_ENABLE_IPC_MODE_LEGACY" in r["env"]
+    assert "distinct_devices" in r["config"]["host"]
+
+
+def test_two_ranks_on_one_device_is_an_invalid_nccl_run(gpu_lib):
+    """Under nccl (= RCCL) two ranks on one GPU did not measure two GPUs: bench.py must refuse to print a result.  The
+    rule is exercised on the gloo rehearsal with RAWDEV_DIAG_ASSUME_NCCL=1 (RCCL itself refuses to start that way)."""
+    out = _bench_raw(["--gpus", "2", "--frames", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-box"],
+                     {"RAWDEV_DIST_BACKEND": "gloo", "RAWDEV_DIAG_ASSUME_NCCL": "1"})
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout      # no result line on stdout
+    assert "INVALID RUN" in out.stderr and "distinct device" in out.stderr
 
 
 def test_node_host_mode_one_process(gpu_lib):
@@ -46,6 +71,7 @@ def test_node_host_mode_one_process(gpu_lib):
     assert r["n_gpus"] == 2 and r["verified"] is True
     assert "rd_node_batch" in r["config"]["host"] and "REHEARSAL" in r["config"]["host"]
     assert r["histogram_call_us"]["median"] > 0 and "host fold" in r["histogram_call_us"]["reduction"]
+    assert [d["device_index"] for d in r["devices"]] == [0, 0] and r["distinct_devices"] == 1 and r["devices"][0]["pci_bus_id"]
     r1 = _bench(["--host", "node", "--gpus", "1", "--frames", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
     assert r1["n_gpus"] == 1 and r1["verified"] is True and "REHEARSAL" not in r1["config"]["host"]
 
@@ -57,9 +83,25 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert "uploads its descriptors" in r["config"]["descriptors"]
     ex = r["extra_configs"]
     assert "error" not in ex, ex
-    for key in ("single_frame_f32", "batch_rgba8", "config5_shape_f16"):
+    for key in ("single_frame_f32", "batch_rgba8", "config5_shape_f16", "config5_shape_f16_tiled"):
         e = ex[key]
         assert e["verified"] is True, (key, e)
         assert e["ms"] > 0 and e["MP_per_s"] > 0
         assert 0 < e["roofline"]["frac"] < 1 and e["roofline"]["achieved"] > 0
-    assert r["cpu_baseline"]["kind"] == "port"
+    assert ex["config5_shape_f16"]["row_bands_effective"] == 1 and ex["config5_shape_f16_tiled"]["row_bands_effective"] == 8
+    assert ex["config5_shape_f16_tiled"]["launches_per_step"] == 16 * 8
+    # the reference's own metric-path entry, as its caller invokes it, and the export ring
+    fr = ex["full_res_to_bytes"]
+    assert fr["verified"] is True, fr
+    assert fr["pcie_floor_ms"] > 0 and "pipeline.rs:525" in fr["reference_published"]
+    for k in ("pinned_dst", "pageable_dst_reused", "pageable_dst_fresh"):
+        assert fr[k]["ms"] > 0 and fr[k]["GBps_over_pcie"] > 0 and fr[k]["limiter"]
+    assert fr["pinned_dst"]["ms"] <= 2.5, fr["pinned_dst"]                     # the bar: a 24 MP export costs the PCIe transfer
+    for k in ("rgb8", "rgba8"):
+        assert ex["export_ring"][k]["verified"] is True and ex["export_ring"][k]["ms_per_frame"] > 0
+    # the box's own ceilings, measured in this run (item 4)
+    rf = r["roofline"]
+    assert rf["box_copy_GBps"] > 3000 and rf["box_fill_GBps"] > 3000 and 0 < rf["frac_of_box_copy"] < 1.2
+    assert r["ranks"][0]["pci_bus_id"] and r["distinct_devices"] == 1 and r["world_size_seen"] == 1
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and "march=native" in cb["build"] and cb["value_portable_O2_build"] > 0

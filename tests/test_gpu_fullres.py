@@ -1,0 +1,156 @@
+"""-m gpu: render_full_res_to_bytes as its caller invokes it (pipeline.rs:526-606; export_image_async, main.rs:1749-1754).
+
+  * the band-pipelined read-back gives the oracle's bytes for a pageable destination (fresh and caller-provided), a
+    page-locked one (rd_host_alloc: the direct-DMA path), surfaces just above the 16 MiB banding threshold, the RGB8 and
+    f32 surfaces and a fused histogram (one launch, chunked copies);
+  * the call does not hold the pipeline's lock: while one thread loops render_full_res_to_bytes on a 24 MP frame,
+    another thread's render_to_bytes (the UI thread's preview, main.rs:1525) keeps a median under 1 ms and stays
+    bit-identical to the oracle;
+  * the uniforms are snapshotted: an export that races rd_update_uniforms is entirely one stack or entirely the other.
+"""
+import statistics
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from tests.helpers import CM_TEST, WB_DAYLIGHT, random_cfa, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle8(refc, cfa, params, tw=None, th=None, zoom=1.0, pan=(0.0, 0.0)):
+    u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST, zoom, pan[0], pan[1])
+    return refc.pack_u8(refc.render_f32(cfa, u, tw, th, nthreads=8))
+
+
+@pytest.mark.parametrize("h,w", [(2056, 2048), (1030, 4224), (2009, 2304)])
+def test_banded_readback_sizes_and_destinations(gpu_lib, refc, h, w):
+    """Surfaces of 16.1-18.5 MiB: eight row bands of unequal height (odd H: the last unit has one row), chunk boundaries
+    inside bands, every kind of destination."""
+    ra = gpu_lib
+    rng = np.random.default_rng([0x52415745, h, w])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = ra.RenderPipeline.new(3, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+    exp = _oracle8(refc, cfa, params)
+    assert np.array_equal(pipe.render_full_res_to_bytes().reshape(h, w, 4), exp), "fresh pageable destination"
+    mine = np.full(h * w * 4, 0x5a, np.uint8)
+    assert pipe.render_full_res_to_bytes(out=mine) is mine
+    assert np.array_equal(mine.reshape(h, w, 4), exp), "caller-provided pageable destination"
+    pin = ra.PinnedBytes(h * w * 4)
+    pin.array[:] = 0xa5
+    pipe.render_full_res_to_bytes(out=pin.array)
+    assert np.array_equal(pin.array.reshape(h, w, 4), exp), "page-locked destination (direct DMA)"
+    pin.free()
+    # the general form: fused histogram (one launch) + chunked copies; the f32 and RGB8 surfaces in bands
+    got8, hist = pipe.render(fmt=ra.FMT_RGBA_U8, with_histogram=True)
+    assert np.array_equal(got8, exp) and np.array_equal(hist, refc.histogram(exp))
+    u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST)
+    f32 = refc.render_f32(cfa, u, nthreads=8)
+    got32 = pipe.render(fmt=ra.FMT_RGBA_F32)
+    assert np.array_equal(got32.view(np.uint32), f32.view(np.uint32))
+    if w % 128 == 0:
+        got3 = pipe.render(fmt=ra.FMT_RGB_U8)
+        assert np.array_equal(got3, exp[..., :3])
+    with pytest.raises(ra.RawdevError):
+        pipe.render_full_res_to_bytes(out=np.empty(h * w * 4 - 4, np.uint8))
+    pipe.close()
+
+
+def test_export_does_not_block_the_ui_thread(gpu_lib, refc):
+    """main.rs:1749-1754 (export on a blocking thread) beside main.rs:1515-1531 (view() on the UI thread), one
+    Arc<RenderPipeline>: 24 MP exports back to back while the other thread renders previews."""
+    ra = gpu_lib
+    h, w = 4016, 6016
+    rng = np.random.default_rng([0x52415745, 77])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = ra.RenderPipeline.new(9, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+    exp_prev = _oracle8(refc, cfa, params, tw=pipe.preview_width, th=pipe.preview_height)
+    exp_full_rows = _oracle8(refc, cfa[:8], params)          # rows 0..5 of the frame only need CFA rows 0..7
+    pin = ra.PinnedBytes(h * w * 4)
+    stop = threading.Event()
+    exports, errors = [], []
+
+    def export_loop():
+        try:
+            k = 0
+            while not stop.is_set():
+                t0 = time.perf_counter()
+                out = pipe.render_full_res_to_bytes(out=pin.array if k % 2 == 0 else None)   # direct DMA / staged, alternating
+                exports.append((time.perf_counter() - t0) * 1e3)
+                if not np.array_equal(out.reshape(h, w, 4)[:6], exp_full_rows[:6]):
+                    errors.append(f"export {k}: first rows differ from the oracle")
+                k += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    # the preview alone (no export running): the baseline of this box
+    for _ in range(5):
+        pipe.render_to_bytes()
+    alone = []
+    for _ in range(40):
+        t0 = time.perf_counter()
+        pipe.render_to_bytes()
+        alone.append((time.perf_counter() - t0) * 1e3)
+    t = threading.Thread(target=export_loop)
+    t.start()
+    while len(exports) < 2 and t.is_alive():                  # both lanes warm (first calls allocate)
+        time.sleep(0.005)
+    beside, bad_preview = [], 0
+    for i in range(120):
+        t0 = time.perf_counter()
+        prev = pipe.render_to_bytes()
+        beside.append((time.perf_counter() - t0) * 1e3)
+        if i % 20 == 0 and not np.array_equal(prev.reshape(exp_prev.shape), exp_prev):
+            bad_preview += 1
+        time.sleep(0.002)
+    n_exports = len(exports)
+    stop.set()
+    t.join()
+    assert not errors, errors
+    assert bad_preview == 0
+    assert n_exports >= 4, f"only {n_exports} exports ran beside the previews"
+    med_alone, med_beside = statistics.median(alone), statistics.median(beside)
+    print(f"\npreview alone {med_alone:.3f} ms; beside back-to-back 24 MP exports {med_beside:.3f} ms (max {max(beside):.3f}); "
+          f"{n_exports} exports, median {statistics.median(exports):.2f} ms")
+    assert med_beside < 1.0, f"preview median {med_beside:.3f} ms while an export runs (alone: {med_alone:.3f} ms)"
+    # and the whole 24 MP surface once, against the oracle
+    full = pipe.render_full_res_to_bytes(out=pin.array).reshape(h, w, 4)
+    assert np.array_equal(full, _oracle8(refc, cfa, params))
+    pin.free()
+    pipe.close()
+
+
+def test_export_races_uniform_updates_without_tearing(gpu_lib, refc):
+    ra = gpu_lib
+    h, w = 2056, 2048
+    rng = np.random.default_rng([0x52415745, 78])
+    cfa = random_cfa(rng, h, w)
+    stacks = [random_params(rng), random_params(rng)]
+    exps = [_oracle8(refc, cfa, s) for s in stacks]
+    pipe = ra.RenderPipeline.new(5, cfa.reshape(-1), w, h, ra.EditParams(**stacks[0]), WB_DAYLIGHT, CM_TEST)
+    stop = threading.Event()
+
+    def drag():
+        k = 0
+        while not stop.is_set():
+            pipe.update_uniforms(ra.EditParams(**stacks[k & 1]))
+            k += 1
+
+    t = threading.Thread(target=drag)
+    t.start()
+    seen = [0, 0]
+    try:
+        for _ in range(24):
+            got = pipe.render_full_res_to_bytes().reshape(h, w, 4)
+            which = [np.array_equal(got, e) for e in exps]
+            assert any(which), "an export mixed two slider stacks (or matches neither)"
+            seen[which.index(True)] += 1
+    finally:
+        stop.set()
+        t.join()
+    assert sum(seen) == 24
+    pipe.close()

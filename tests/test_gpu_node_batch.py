@@ -98,24 +98,23 @@ def test_node_batch_rccl_leg_with_one_rank(gpu_lib, refc, monkeypatch):
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STANDIN_SRC = os.path.join(ROOT, "tests", "cpp", "rccl_standin.cpp")
-STANDIN_SO = os.path.join(ROOT, "tests", "cpp", "librccl_standin.so")
-
-
-def build_rccl_standin() -> str:
-    """tests/cpp/rccl_standin.cpp -> tests/cpp/librccl_standin.so (host code over the HIP runtime; hipcc, a few seconds)."""
-    if not os.path.exists(STANDIN_SO) or os.path.getmtime(STANDIN_SO) < os.path.getmtime(STANDIN_SRC):
-        hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
-        subprocess.run([hipcc, "-O1", "-fPIC", "-shared", "-o", STANDIN_SO, STANDIN_SRC], check=True)
-    return STANDIN_SO
+from tests.cpp.build_standin import build_rccl_standin  # noqa: E402  (no pytest in there: __graft_entry__.build() uses it too)
 
 
 def test_node_batch_rccl_branch_with_several_ranks_through_the_standin(gpu_lib):
     """The RCCL branch of rd_node_batch (ncclCommInitAll, the grouped in-place ncclAllReduce loop, 'every device holds the
     sum') with n = 2 and 4 ranks on ONE GPU, through a host-memory stand-in for librccl (tests/cpp/rccl_standin.cpp).
-    A fresh process: librawdev binds its RCCL library once.  Test infrastructure -- says nothing about RCCL / xGMI."""
-    env = dict(os.environ, RAWDEV_RCCL_LIB=build_rccl_standin())
-    env.pop("RD_NODE_REDUCE", None)
+    A fresh process: librawdev binds its RCCL library once.  Test infrastructure -- says nothing about RCCL / xGMI.
+    Naming the stand-in alone (RAWDEV_RCCL_LIB without RD_NODE_REDUCE=standin) must NOT relax the one-rank-per-device rule."""
+    ra = gpu_lib
+    env0 = dict(os.environ, RAWDEV_RCCL_LIB=build_rccl_standin())
+    env0.pop("RD_NODE_REDUCE", None)
+    probe = ("import raweditor_amd as ra\n"
+             "try:\n    ra.NodeBatch([0, 0], 64, 34, ra.FMT_RGBA_U8)\n    print('accepted')\n"
+             "except ra.RawdevError as e:\n    print('refused', e.code)\n")
+    out0 = subprocess.run([sys.executable, "-c", probe], env=env0, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert "refused" in out0.stdout, out0.stdout + out0.stderr
+    env = dict(os.environ, RAWDEV_RCCL_LIB=build_rccl_standin(), RD_NODE_REDUCE="standin")   # the explicit opt-in
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "node_rccl_standin_run.py")], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr

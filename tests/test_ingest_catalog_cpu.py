@@ -423,16 +423,24 @@ def test_ljpeg_truncated_stream_declaring_a_huge_frame_fails_fast_and_small(rng)
         ingest.ljpeg_decode(bytes(huge), max_samples=16 * 8)      # the tile holds 128 samples
     with pytest.raises(ValueError, match="Failed to decode RAW"):
         ingest.ljpeg_decode(bytes(huge))                          # no tile size known: the module's own ceiling
+    with pytest.raises(ValueError, match="Failed to decode RAW"):
+        ingest.ljpeg_decode(bytes(huge), max_samples=1 << 31)     # a single-strip DNG's w*h: a caller's limit never LOOSENS the
     peak = tracemalloc.get_traced_memory()[1]
     tracemalloc.stop()
     assert time.time() - t0 < 2.0 and peak < (8 << 20), (time.time() - t0, peak)
-    # within the ceiling but far longer than the data: must stop at the first dry row, not after 4096 rows of zeros
+    #                                                               module ceiling, nor the stream's own bound (>= 1 bit per sample)
+    # within every bound but longer than the data: must stop at the first dry row, not after the declared rows of zeros
+    rows = 8 * len(good) // 16 - 1                                # as many rows as the stream's byte count could possibly hold
+    assert rows > 16
     tall = bytearray(good)
-    tall[i + 5:i + 7] = struct.pack(">H", 4096)
+    tall[i + 5:i + 7] = struct.pack(">H", rows)
     t0 = time.time()
     with pytest.raises(ValueError, match="truncated"):
         ingest.ljpeg_decode(bytes(tall))
     assert time.time() - t0 < 1.0
+    tall[i + 5:i + 7] = struct.pack(">H", 4096)                   # more samples than bits in the stream: refused outright
+    with pytest.raises(ValueError, match="can hold"):
+        ingest.ljpeg_decode(bytes(tall))
 
 
 def test_ljpeg_frame_header_is_found_by_walking_segments_not_by_searching_bytes(rng):

@@ -240,3 +240,37 @@ def test_power_of_two_scaling_properties(refc, rng):
         b = c_render(refc, cfa, p, tuple(2 * x for x in WB_DAYLIGHT), CM_TEST)
         c = c_render(refc, (cfa * 2).astype(np.uint16), p, WB_DAYLIGHT, CM_TEST)
         assert ulp_diff(a, b) == 0 and ulp_diff(a, c) == 0
+
+
+def test_native_build_of_the_oracle_is_bit_identical(refc, rng):
+    """bench.py's cpu_baseline times the oracle compiled as SURVEY.md section 8d states (-O3 -march=native, contraction
+    off, no fast-math; oracle/Makefile `native`, built on the machine that runs it).  Same source, other optimiser
+    settings and vector ISA: every output bit must be the same as the portable -O2 checker's -- if -march=native changed
+    one, that would be a finding about the restatement (an operation whose order the text does not pin)."""
+    import ctypes as C
+    native = refc.lib_native()
+    plain = refc.lib()
+    assert native is not plain
+    for trial, (h, w) in enumerate([(37, 64), (64, 130), (5, 7)]):
+        cfa = random_cfa(rng, h, w, hi=65536 if trial == 2 else 4096)
+        for math in (refc.MATH_STRICT, refc.MATH_CONTRACTED):
+            u = refc.make_uniforms(random_params(rng), WB_DAYLIGHT, CM_TEST, math_mode=math,
+                                   zoom=1.0 if trial != 1 else 1.7, pan_x=0.0 if trial != 1 else 0.1)
+            outs = []
+            for L in (plain, native):
+                out = np.empty((h, w, 4), np.float32)
+                L.ref_render_f32(cfa.ctypes.data_as(C.POINTER(C.c_uint16)), w, h, C.byref(u), w, h, refc.POW_PINNED,
+                                 out.ctypes.data_as(C.POINTER(C.c_float)))
+                outs.append(out)
+            assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (trial, math)
+    # and the golden vectors' expected bytes come out of the native build too
+    from tests.golden_util import load_golden
+    for case in load_golden():
+        cfa = np.ascontiguousarray(case["cfa"])
+        h, w = cfa.shape
+        u = refc.make_uniforms(case["params"], case["wb"], case["cm"], case["zoom"], *case["pan"], case["black_level"])
+        tw, th = case["tw"] or w, case["th"] or h
+        out = np.empty((th, tw, 4), np.float32)
+        native.ref_render_f32(cfa.ctypes.data_as(C.POINTER(C.c_uint16)), w, h, C.byref(u), tw, th, refc.POW_PINNED,
+                              out.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(out.view(np.uint32), case["f32"].view(np.uint32)), case["name"]

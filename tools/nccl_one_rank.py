@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The collective calls bench.py makes when N > 1, on a ONE-rank nccl (= RCCL) process group: init_process_group with
 device_id, the i64[768] histogram all-reduce (counts beyond 2^33 survive), barrier, the f64 MAX reduce of the elapsed
-time.  What a one-GPU box can rehearse of the RCCL leg of `bench.py --gpus N`; the multi-rank path itself is covered over
+time, the all_gather_object of the per-rank records.  What a one-GPU box can rehearse of the RCCL leg of `bench.py --gpus N`; the multi-rank path itself is covered over
 gloo (tests/test_distributed_cpu.py, `RAWDEV_DIST_BACKEND=gloo`)."""
 import os
 import sys
@@ -29,7 +29,9 @@ def main():
         torch.cuda.synchronize()
         t = torch.tensor([1.5], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ok = int(h[767].item()) == 767 * 2 ** 33 and float(t.item()) == 1.5
+        got = [None]
+        dist.all_gather_object(got, {"rank": 0, "pci_bus_id": "x", "MP_per_s": 1.0})   # the per-rank records of the N > 1 line
+    ok = int(h[767].item()) == 767 * 2 ** 33 and float(t.item()) == 1.5 and got[0]["pci_bus_id"] == "x"
     dist.destroy_process_group()
     print("nccl one-rank rehearsal", "ok" if ok else "FAILED")
     return 0 if ok else 1
