@@ -343,10 +343,11 @@ def measure_box(ra, dev_index):
     hipMemcpyDtoD/stream-triad ceiling on the box'): librawdev's float4 copy / nt fill / read kernels over 1 GiB, median of 5."""
     try:
         t0 = time.perf_counter()
-        c, f, r = ra.measure_hbm(dev_index, 1 << 30, 5)
-        return {"copy": round(c, 1), "fill": round(f, 1), "read": round(r, 1), "seconds": round(time.perf_counter() - t0, 2)}
+        c, f, r, m = ra.measure_hbm(dev_index, 1 << 30, 5)
+        return {"copy": round(c, 1), "fill": round(f, 1), "read": round(r, 1), "memset": round(m, 1),
+                "seconds": round(time.perf_counter() - t0, 2)}
     except Exception as e:  # noqa: BLE001
-        return {"copy": None, "fill": None, "read": None, "error": str(e)}
+        return {"copy": None, "fill": None, "read": None, "memset": None, "error": str(e)}
 
 
 def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform"):
@@ -427,9 +428,11 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
             "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBPS, 4),      # reported beside `frac`, never instead of it
             # this box, this run, before the headline (rd_measure_hbm: float4 copy / nt fill / read of 1 GiB, median of 5)
             "box_copy_GBps": box.get("copy"), "box_fill_GBps": box.get("fill"), "box_read_GBps": box.get("read"),
+            "box_memset_GBps": box.get("memset"),
             "frac_of_box_copy": round(achieved / box["copy"], 4) if box.get("copy") else None,
             "frac_of_box_fill": round(achieved / box["fill"], 4) if box.get("fill") else None,
-            "box_note": "the guide's 6290 GB/s copy figure stays in frac_of_copy_ceiling; box_* are measured on this device in this run",
+            "box_note": "the guide's 6290 GB/s copy figure stays in frac_of_copy_ceiling; box_* are measured on this device in this run "
+                        "(copy counts bytes read + written; this kernel writes 16 of its 18 B/px, so it sits between the copy and the fill ceiling)",
             "kernel": "rd_develop_batch" if multi else "rd_develop_quads",
             "launch_us": round(launch_us, 2), "frames_per_launch": round(F / lpc, 3), "us_per_frame": round(frame_us, 2),
             "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "

@@ -317,9 +317,11 @@ int rd_host_alloc(int device, size_t bytes, void **out);
 int rd_host_free(int device, void *ptr);
 /* Measurement aid (bench.py's roofline.box_*): what THIS device streams right now, with librawdev's own trivial kernels --
  * a float4 copy of `bytes` to another buffer (GB/s counts the bytes read plus the bytes written), a non-temporal float4
- * fill and a float4 read of `bytes`; each launched `reps` times on a private stream, the median launch reported.  Any
- * output may be NULL.  Allocates 2 x bytes of device memory for the call. */
-int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps);
+ * fill and a float4 read of `bytes` (a wave walks its own contiguous range, eight 1-KiB accesses in flight: the fastest
+ * shape tools/hbm_probe.hip finds) and hipMemsetAsync beside them; each launched `reps` times on a private stream, the
+ * median launch reported.  Any output may be NULL.  Allocates 2 x bytes of device memory for the call. */
+int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
+                   double *memset_GBps);
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);
 int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes);

@@ -101,7 +101,7 @@ PROTOTYPES = {
     "rd_ljpeg_decode": (_I, [_VP, _SZ, _VP, _SZ, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "rd_host_alloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_host_free": (_I, [_I, _VP]),
-    "rd_measure_hbm": (_I, [_I, _SZ, _U32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rd_measure_hbm": (_I, [_I, _SZ, _U32] + [C.POINTER(C.c_double)] * 4),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_device_free": (_I, [_I, _VP]),
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -833,6 +834,27 @@ static bool rd_is_pinned_host(const void *ptr, size_t n)
     return true;
 }
 
+// A pageable destination that has never been touched (the fresh Vec<u8> the reference's signature returns) costs one page
+// fault per 4 KiB inside the staging memcpy: 23 600 faults for a 24 MP RGBA8 surface, several times the PCIe transfer.
+// Two hints were tried on the GPU box (THP mode "madvise", kernel 6.18; profiles/r04_fullres_ab.txt) and neither pays:
+// MADV_HUGEPAGE on the 2 MiB-aligned interior (46 faults instead of 23 600, but each compacts and zeroes 2 MiB: 8.0 ms
+// against 6.5 ms without it) and MADV_POPULATE_WRITE (7.9 ms).  So the default is to do nothing -- the faults are the
+// caller's, a reused or page-locked destination avoids them -- and RD_DST_ADVISE=huge | populate keeps the experiment.
+static void rd_advise_destination(char *dst, size_t n)
+{
+    static const int mode = [] { const char *e = getenv("RD_DST_ADVISE"); return !e || !*e ? 0 : !strcmp(e, "huge") ? 1 : !strcmp(e, "populate") ? 2 : 0; }();
+    if (!mode || n < ((size_t)8 << 20)) return;
+    const uintptr_t huge = (uintptr_t)2 << 20;
+    const uintptr_t lo = ((uintptr_t)dst + huge - 1) & ~(huge - 1), hi = ((uintptr_t)dst + n) & ~(huge - 1);
+    if (hi <= lo) return;
+#ifdef MADV_HUGEPAGE
+    if (mode == 1) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+#endif
+#ifdef MADV_POPULATE_WRITE
+    if (mode == 2) (void)madvise((void *)lo, hi - lo, MADV_POPULATE_WRITE);
+#endif
+}
+
 // Full-resolution host render (render_full_res_to_bytes, pipeline.rs:526-606, and rd_render of the whole frame): the
 // reference renders, copies the texture into a MAP_READ buffer, blocks in poll(Wait) and de-pads 96.6 MB row by row
 // ("1-2 seconds for 24MP", pipeline.rs:525).  Here, on the lane's two streams:
@@ -891,6 +913,7 @@ static int rd_render_full_host(rd_pipeline *p, rd_lane *l, const rd_shot &sh, ui
             if (e == hipSuccess) e = hipEventRecord(l->cev[c], l->copy);
         }
         rd_copy_pool &pool = rd_copy_pool::get();
+        rd_advise_destination(dst, need);
         for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
             const size_t j = c % RD_STAGE_SLOTS, off = c * chunk, len = need - off < chunk ? need - off : chunk;
             e = hipEventSynchronize(l->cev[j]);
@@ -1881,38 +1904,61 @@ extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, si
 // measurement aid: the streaming ceilings of THIS device, now (bench.py: roofline.box_copy_GBps / box_fill_GBps)
 // ------------------------------------------------------------------------------------------------
 // Boxes of one pool differ by a few per cent (power-managed clocks), and SURVEY.md section 8d asks for the roofline
-// fraction against a ceiling measured on the box, not only against the 8 TB/s of the data sheet.  Three trivial
-// persistent kernels, 16 B per lane and access, 2048 workgroups x 256 threads: copy (plain loads, nt stores), fill (nt
-// stores), read (loads folded into a value nobody needs).
-__global__ void __launch_bounds__(256) rd_probe_copy(const rd_f4 *__restrict__ src, rd_f4 *__restrict__ dst, size_t n)
+// fraction against a ceiling measured on the box, not only against the 8 TB/s of the data sheet.  Three trivial kernels,
+// 16 B per lane and access, eight accesses in flight per lane; a WAVE walks its own contiguous range (1 KiB per
+// instruction, 8 KiB per step).  That shape is the fastest of the ones tools/hbm_probe.hip tries (profiles/r04_hbm_probe.txt:
+// copy 5.72 TB/s, fill 6.11 TB/s against 4.9 / 4.9 TB/s for a grid-stride loop with the same accesses in flight and
+// 5.0 / 4.2 TB/s for the one-access grid-stride loop this function started with); hipMemsetAsync is reported beside them.
+#define RD_PROBE_U 8
+__global__ void __launch_bounds__(1024) rd_probe_copy(const rd_f4 *__restrict__ src, rd_f4 *__restrict__ dst, size_t per_wave)
 {
-    const size_t stride = (size_t)gridDim.x * 256u;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(src[i], dst + i);
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    for (size_t i = w * per_wave; i < (w + 1) * per_wave; i += 64u * RD_PROBE_U) {
+        rd_f4 v[RD_PROBE_U];
+#pragma unroll
+        for (int k = 0; k < RD_PROBE_U; ++k) v[k] = src[i + (size_t)k * 64u + lane];
+#pragma unroll
+        for (int k = 0; k < RD_PROBE_U; ++k) __builtin_nontemporal_store(v[k], dst + i + (size_t)k * 64u + lane);
+    }
 }
 
-__global__ void __launch_bounds__(256) rd_probe_fill(rd_f4 *__restrict__ dst, size_t n, float v)
+__global__ void __launch_bounds__(1024) rd_probe_fill(rd_f4 *__restrict__ dst, size_t per_wave, float x)
 {
-    const size_t stride = (size_t)gridDim.x * 256u;
-    const rd_f4 x = { v, v + 1.0f, v + 2.0f, 1.0f };
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(x, dst + i);
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const rd_f4 v = { x, x + 1.0f, x + 2.0f, 1.0f };
+    for (size_t i = w * per_wave; i < (w + 1) * per_wave; i += 64u * RD_PROBE_U) {
+#pragma unroll
+        for (int k = 0; k < RD_PROBE_U; ++k) __builtin_nontemporal_store(v, dst + i + (size_t)k * 64u + lane);
+    }
 }
 
-__global__ void __launch_bounds__(256) rd_probe_read(const rd_f4 *__restrict__ src, size_t n, float *sink)
+__global__ void __launch_bounds__(1024) rd_probe_read(const rd_f4 *__restrict__ src, size_t per_wave, float *sink)
 {
-    const size_t stride = (size_t)gridDim.x * 256u;
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     float acc = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) { const rd_f4 v = src[i]; acc += v.x + v.y + v.z + v.w; }
+    for (size_t i = w * per_wave; i < (w + 1) * per_wave; i += 64u * RD_PROBE_U) {
+        rd_f4 v[RD_PROBE_U];
+#pragma unroll
+        for (int k = 0; k < RD_PROBE_U; ++k) v[k] = src[i + (size_t)k * 64u + lane];
+#pragma unroll
+        for (int k = 0; k < RD_PROBE_U; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
     if (acc == 12345.678f) *sink = acc;                      // never true for the zeroed buffer: keeps the loads alive
 }
 
-extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps)
+extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
+                              double *memset_GBps)
 {
-    if (bytes < (1u << 20) || !reps || reps > 64) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need >= 1 MiB and 1..64 repetitions");
+    if (bytes < ((size_t)64 << 20) || !reps || reps > 64) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need >= 64 MiB and 1..64 repetitions");
     int rc = rd_check_device(device, nullptr);
     if (rc) return rc;
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    const size_t n = bytes / sizeof(rd_f4);
+    // copy: 4096 x 16 waves, fill / read: 2048 x 16 waves; every wave owns a whole number of 8-KiB steps
+    const uint32_t blocks[3] = { 4096u, 2048u, 2048u };
+    const size_t step = 64u * RD_PROBE_U;                                        // float4 per wave and step
+    const size_t per_wave_max = bytes / sizeof(rd_f4) / (2048u * 16u) / step * step;
+    const size_t n = per_wave_max * 2048u * 16u;                                  // float4 actually moved (both grids divide it)
     void *a = nullptr, *b = nullptr;
     float *sink = nullptr;
     hipStream_t s = nullptr;
@@ -1925,14 +1971,16 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * sizeof(rd_f4), s);
     if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(rd_f4), s);
-    double out[3] = { 0.0, 0.0, 0.0 };
-    for (int which = 0; which < 3 && e == hipSuccess; ++which) {
+    double out[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (int which = 0; which < 4 && e == hipSuccess; ++which) {
         std::vector<float> ms;
+        const size_t per_wave = which < 3 ? n / ((size_t)blocks[which] * 16u) : 0;
         for (uint32_t r = 0; r < reps + 1u && e == hipSuccess; ++r) {             // the first launch warms up
             e = hipEventRecord(e0, s);
-            if (which == 0) hipLaunchKernelGGL(rd_probe_copy, dim3(2048), dim3(256), 0, s, (const rd_f4 *)a, (rd_f4 *)b, n);
-            else if (which == 1) hipLaunchKernelGGL(rd_probe_fill, dim3(2048), dim3(256), 0, s, (rd_f4 *)b, n, (float)r);
-            else hipLaunchKernelGGL(rd_probe_read, dim3(2048), dim3(256), 0, s, (const rd_f4 *)a, n, sink);
+            if (which == 0) hipLaunchKernelGGL(rd_probe_copy, dim3(blocks[0]), dim3(1024), 0, s, (const rd_f4 *)a, (rd_f4 *)b, per_wave);
+            else if (which == 1) hipLaunchKernelGGL(rd_probe_fill, dim3(blocks[1]), dim3(1024), 0, s, (rd_f4 *)b, per_wave, (float)r);
+            else if (which == 2) hipLaunchKernelGGL(rd_probe_read, dim3(blocks[2]), dim3(1024), 0, s, (const rd_f4 *)a, per_wave, sink);
+            else if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(rd_f4), s);
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(e1, s);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1956,6 +2004,7 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
     if (copy_GBps) *copy_GBps = out[0];
     if (fill_GBps) *fill_GBps = out[1];
     if (read_GBps) *read_GBps = out[2];
+    if (memset_GBps) *memset_GBps = out[3];
     return RD_OK;
 }
 

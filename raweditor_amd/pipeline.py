@@ -80,8 +80,8 @@ class PinnedBytes:
 
 
 def measure_hbm(device: int = 0, nbytes: int = 1 << 30, reps: int = 5):
-    """(copy, fill, read) GB/s of this device right now with librawdev's own streaming kernels (rd_measure_hbm)."""
-    v = [C.c_double() for _ in range(3)]
+    """(copy, fill, read, hipMemsetAsync) GB/s of this device right now (rd_measure_hbm: librawdev's own streaming kernels)."""
+    v = [C.c_double() for _ in range(4)]
     check(_lib.lib().rd_measure_hbm(int(device), int(nbytes), int(reps), *[C.byref(x) for x in v]))
     return tuple(x.value for x in v)
 
