@@ -120,13 +120,14 @@ extern "C" uint32_t rd_elided_steps(const rd_edit_params *p, const float wb[4], 
 // ------------------------------------------------------------------------------------------------
 // device bookkeeping
 // ------------------------------------------------------------------------------------------------
-struct rd_devguard {
+struct rd_devguard {                             // the calling thread's current device, for the scope of one entry point
     int prev = -1;
     bool ok = false;
     explicit rd_devguard(int dev)
     {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) { ok = true; prev = -1; }           // already current (the usual case): nothing to set, nothing to restore
+        else ok = hipSetDevice(dev) == hipSuccess;
     }
     ~rd_devguard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
@@ -286,40 +287,53 @@ struct rd_scratch {
     }
 };
 
+// One launch of rd_develop_quads as data: the kernel instance, its grid and its 14 arguments.  rd_launch_quads_t fills
+// one and either launches it or hands it back (`record`) so that the caller can put it into a graph node.
+struct rd_quads_call {
+    const void *fn = nullptr;
+    uint32_t blocks = 0;
+    const uint16_t *cfa; void *out; uint32_t W, H, unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax; uint32_t *tq; rd_ku u;
+    uint32_t *slab32; unsigned long long *slab64;
+    void *argv[14];
+    void bind()
+    {
+        void *a[14] = { &cfa, &out, &W, &H, &unit0, &unit1, &tpu, &tpu_magic, &tq_k, &tq_tmax, &tq, &u, &slab32, &slab64 };
+        memcpy(argv, a, sizeof a);
+    }
+};
+
 template <int FMT, bool HIST, int MATH>
 static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t unit0,
                               uint32_t unit1, uint32_t blocks, const rd_ku &u_in, uint32_t *slab32,
-                              unsigned long long *slab64, uint32_t *tq, hipStream_t s)
+                              unsigned long long *slab64, uint32_t *tq, hipStream_t s, rd_quads_call *record)
 {
     static const bool no_elide = rd_env_u32("RD_NO_ELIDE", 0) != 0;    // A/B switch: evaluate every step (rd_uniforms.h RD_EL_*)
-    rd_ku u = u_in;
-    if (no_elide) u.elide = 0u;
+    rd_quads_call local;
+    rd_quads_call &c = record ? *record : local;
+    c.u = u_in;
+    if (no_elide) c.u.elide = 0u;
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
-    const uint32_t tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;   // rd_kernels.h: split()
+    c.tpu = tpu;
+    c.tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;   // rd_kernels.h: split()
     const uint32_t nwaves = blocks * RD_WAVES;
     const uint32_t ntiles = (unit1 - unit0) * tpu;
     // ticket counters: groups of RD_TQ_CLIENTS waves need gridDim % 16 == 0 (rd_blocks_for rounds to that); else one counter
     static const bool static_deal = rd_env_u32("RD_STATIC_DEAL", 0) != 0;                 // A/B switch: no tickets
-    const uint32_t tq_k = static_deal ? 0u : (blocks >= 16u && blocks % 16u == 0u) ? blocks / 4u : 1u;
+    c.tq_k = static_deal ? 0u : (blocks >= 16u && blocks % 16u == 0u) ? blocks / 4u : 1u;
     const uint32_t ndyn = ntiles > nwaves ? ntiles - nwaves : 0u;
-    const uint32_t tq_tmax = tq_k ? (ndyn + tq_k - 1u) / tq_k : 0u;
+    c.tq_tmax = c.tq_k ? (ndyn + c.tq_k - 1u) / c.tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;   // A/B override: 0 / 1
     // read burst (rd_kernels.h): f32 surface by default; needs 16-byte aligned CFA rows and a launch worth it
     const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
     const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && (burst_env < 0 || burst_env != 0);
+    c.blocks = blocks; c.cfa = cfa; c.out = out; c.W = W; c.H = H; c.unit0 = unit0; c.unit1 = unit1; c.tq = tq;
+    c.slab32 = slab32; c.slab64 = slab64;
+    c.fn = W % 128u == 0 ? (const void *)rd_develop_quads<FMT, HIST, true, MATH, false> : (const void *)rd_develop_quads<FMT, HIST, false, MATH, false>;
     if constexpr (FMT == RD_FMT_RGBA_F32) {     // the burst variant exists for the f32 surface only
-        if (W % 128u == 0 && burst) {
-            hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                               unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u, slab32, slab64);
-            return;
-        }
+        if (W % 128u == 0 && burst) c.fn = (const void *)rd_develop_quads<FMT, HIST, true, MATH, true>;
     }
-    if (W % 128u == 0)
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, true, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                           unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u, slab32, slab64);
-    else
-        hipLaunchKernelGGL((rd_develop_quads<FMT, HIST, false, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, cfa, out, W, H,
-                           unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u, slab32, slab64);
+    c.bind();
+    if (!record) (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
 }
 
 // Multi-frame launch (rd_develop_batch): descs_dev[0 .. nframes-1] are whole frames of W x H.
@@ -400,7 +414,7 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
                              uint32_t tw, uint32_t th, uint32_t fmt, void *out, const rd_ku &u,
                              bool use_quads, uint32_t unit0, uint32_t unit1, bool hist, uint32_t math,
                              uint32_t *slab32, unsigned long long *slab64, uint32_t fixed_blocks,
-                             uint32_t *tq, hipStream_t s, uint32_t *blocks_out)
+                             uint32_t *tq, hipStream_t s, uint32_t *blocks_out, rd_quads_call *record = nullptr)
 {
     uint32_t blocks;
     (void)hipGetLastError();                     // HIP's last-error slot is sticky per thread: what is read after the launch
@@ -410,8 +424,9 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
         const uint64_t items = (uint64_t)(unit1 - unit0) * (((W >> 1) + 63u) / 64u) * 64u;   // lanes
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
-        RD_DISPATCH(rd_launch_quads_t, fmt, hist, math, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, tq, s);
+        RD_DISPATCH(rd_launch_quads_t, fmt, hist, math, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, tq, s, record);
     } else {
+        if (record) return rd_fail(RD_ERR_INVALID_ARG, "only the export kernel can be recorded");
         const uint64_t items = (uint64_t)tw * th;
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "target too large for 32-bit pixel index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
@@ -552,6 +567,14 @@ struct rd_pipeline {
     std::mutex lane_mu;               // the lane pool
     std::condition_variable lane_cv;
     std::vector<rd_lane *> lanes;
+    // RD_GRAPH=1 (experiment, profiles/r04_single_frame_gap.txt): develop + histogram fold of a whole-frame render as ONE
+    // two-node graph per stream, re-parameterised (hipGraphExecKernelNodeSetParams) and launched per call
+    struct graph_cache {
+        hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr; hipGraphNode_t n_dev = nullptr, n_fold = nullptr;
+        const void *fn = nullptr; uint32_t blocks = 0;
+    };
+    std::mutex graph_mu;
+    std::map<hipStream_t, graph_cache> graphs;
 };
 
 static void rd_lane_free(rd_lane *l)             // device set, nothing of the lane in flight
@@ -708,6 +731,8 @@ extern "C" void rd_pipeline_destroy(rd_pipeline *p)
         rd_devguard g(p->device);
         for (rd_lane *l : p->lanes) rd_lane_free(l);
         p->lanes.clear();
+        for (auto &kv : p->graphs) { if (kv.second.ex) (void)hipGraphExecDestroy(kv.second.ex); if (kv.second.g) (void)hipGraphDestroy(kv.second.g); }
+        p->graphs.clear();
         if (p->owns_cfa && p->cfa) (void)hipFree((void *)p->cfa);
         (void)hipDeviceSynchronize();        // renders enqueued on caller streams (rd_render_device) may still draw tickets
         p->scratch.release();
@@ -798,6 +823,43 @@ static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, u
     uint32_t blocks = 0;
     const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    static const bool use_graph = rd_env_u32("RD_GRAPH", 0) != 0;
+    if (use_graph && quads && hist_dev && unit0 == 0u && unit1 == H / 2u + 1u) {
+        rd_quads_call call;
+        int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, sh.u, true, unit0, unit1, true, sh.math_mode,
+                                   l.slab32, nullptr, 0, l.tq, s, &blocks, &call);
+        if (rc == RD_OK) {
+            uint32_t *slab = l.slab32, nb = blocks, *hd = hist_dev;
+            void *fold_args[3] = { &slab, &nb, &hd };
+            hipKernelNodeParams kd{}, kf{};
+            kd.func = const_cast<void *>(call.fn); kd.gridDim = dim3(call.blocks); kd.blockDim = dim3(RD_BLOCK); kd.kernelParams = call.argv;
+            kf.func = (void *)rd_reduce_slab32; kf.gridDim = dim3(24); kf.blockDim = dim3(RD_FOLD_THREADS); kf.kernelParams = fold_args;
+            std::lock_guard<std::mutex> gl(p->graph_mu);
+            if (p->graphs.size() > 16 && !p->graphs.count(s)) {              // bounded like the scheduler state
+                for (auto &kv : p->graphs) { if (kv.second.ex) (void)hipGraphExecDestroy(kv.second.ex); if (kv.second.g) (void)hipGraphDestroy(kv.second.g); }
+                p->graphs.clear();
+            }
+            rd_pipeline::graph_cache &gc = p->graphs[s];
+            hipError_t e = hipSuccess;
+            if (!gc.ex || gc.fn != call.fn || gc.blocks != call.blocks) {
+                if (gc.ex) (void)hipGraphExecDestroy(gc.ex);
+                if (gc.g) (void)hipGraphDestroy(gc.g);
+                gc = rd_pipeline::graph_cache{};
+                e = hipGraphCreate(&gc.g, 0);
+                if (e == hipSuccess) e = hipGraphAddKernelNode(&gc.n_dev, gc.g, nullptr, 0, &kd);
+                if (e == hipSuccess) e = hipGraphAddKernelNode(&gc.n_fold, gc.g, &gc.n_dev, 1, &kf);
+                if (e == hipSuccess) e = hipGraphInstantiate(&gc.ex, gc.g, nullptr, nullptr, 0);
+                gc.fn = call.fn; gc.blocks = call.blocks;
+            } else {
+                e = hipGraphExecKernelNodeSetParams(gc.ex, gc.n_dev, &kd);
+                if (e == hipSuccess) e = hipGraphExecKernelNodeSetParams(gc.ex, gc.n_fold, &kf);
+            }
+            if (e == hipSuccess) e = hipGraphLaunch(gc.ex, s);
+            if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "graph launch failed: %s", hipGetErrorString(e));
+        }
+        p->scratch.used(l, s, rc != RD_OK);
+        return rc;
+    }
     int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, sh.u, quads, unit0, unit1,
                                hist_dev != nullptr, sh.math_mode, l.slab32, nullptr, 0, l.tq, s, &blocks);
     if (rc == RD_OK && hist_dev) {
