@@ -350,6 +350,49 @@ def measure_box(ra, dev_index):
         return {"copy": None, "fill": None, "read": None, "memset": None, "error": str(e)}
 
 
+def isa_budget(fmt_name):
+    """Static VALU budget of the export kernel's main loop for this surface (profiles/isa_budget.json, written by
+    tools/isa_budget.py --json from hipcc's own assembly of the bench workload's path), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_budget.json")) as fh:
+            return json.load(fh)["kernels"].get(fmt_name)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def measure_valu_ns(ra, dev_index):
+    try:
+        return ra.measure_valu(dev_index)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def valu_fields(fmt_name, W, H, us_per_frame, valu_ns, n_simd=1024):
+    """The OTHER roofline of the export kernel: VALU issue.  issue time per frame = the kernel's static issue budget per tile
+    (profiles/isa_budget.json, in cycles where a full-rate instruction costs 2) x tiles per frame / SIMDs, priced with what
+    a full-rate instruction costs a SIMD of this device in this run (rd_measure_valu, `valu_ns`); valu_issue_frac = that /
+    the measured time per frame.  Reported BESIDE the HBM fraction, never instead of it."""
+    b = isa_budget(fmt_name)
+    if not b or not valu_ns:
+        return {"valu_issue_frac": None, "valu_note": "profiles/isa_budget.json or rd_measure_valu unavailable"}
+    tiles = (H // 2 + 1) * ((W // 2 + 63) // 64)
+    issue_us = b["issue_cycles"] / 2.0 * valu_ns * tiles / n_simd / 1e3
+    return {"valu_issue_frac": round(issue_us / us_per_frame, 4), "valu_issue_us_per_frame": round(issue_us, 2),
+            "valu_issue_cycles_per_tile": b["issue_cycles"], "valu_instructions_per_tile": b["valu_instructions"],
+            "valu_ns_per_full_rate_instruction": round(valu_ns, 4), "valu_effective_GHz": round(2.0 / valu_ns, 3),
+            "valu_source": f"profiles/isa_budget.json [{b['kernel']}] (static count from hipcc's assembly, bench workload's path) priced with "
+                           "rd_measure_valu of this run; static issue bound: stalls, LDS and memory waits come on top"}
+
+
+def bound_of(fmt_name, hbm_frac, valu):
+    """Which roofline binds: the narrow surfaces are VALU-issue-bound (their HBM traffic is ~1.0x algorithmic and they speed
+    up with fewer instructions, not with fewer bytes); the f32 surface is HBM-bound with the VALU co-critical."""
+    vf = valu.get("valu_issue_frac")
+    if fmt_name != "f32":
+        return "valu"
+    return "hbm" if vf is None or hbm_frac >= 0.6 else "valu"
+
+
 def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform"):
     """Synthetic frames generated on the device, keyed by (seed, global frame index = first_index + f * stride)."""
     cfas, params = [], []
@@ -385,7 +428,8 @@ def workload_label(W, H, world, F):
     return "custom frame size"
 
 
-def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, verified_note, host_note, descriptors_note, box=None):
+def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, verified_note, host_note, descriptors_note, box=None,
+                valu_ns=None):
     total_px = float(world) * F * W * H * args.steps
     launches = args.steps * lpc
     launch_us = dev_ms * 1e3 / launches                    # avg fused-launch period incl. gaps and folds
@@ -396,6 +440,7 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
     per_frame, traffic_source = pmc_traffic(args.format, W, H, "multi" if multi else "per_frame")
     traffic = int(per_frame * F / lpc) if per_frame is not None else None       # per launch, like `achieved`
     box = box or {}
+    valu = valu_fields(args.format, W, H, frame_us, valu_ns)
     return {
         "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
         "value": round(total_px / 1e6 / elapsed, 1),
@@ -422,8 +467,8 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
             "parallelism": f"frames sharded round-robin over {world} GPU(s); RCCL all-reduce of the u64[768] histogram only",
         },
         "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "bound": bound_of(args.format, achieved / HBM_PEAK_GBPS, valu), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, **valu,
             "traffic_source": traffic_source,
             "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBPS, 4),      # reported beside `frac`, never instead of it
             # this box, this run, before the headline (rd_measure_hbm: float4 copy / nt fill / read of 1 GiB, median of 5)
@@ -445,11 +490,13 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
 # ------------------------------------------------------------------------------------------------
 # extra_configs (N = 1): the other BASELINE configurations, in the driver-timed record
 # ------------------------------------------------------------------------------------------------
-def roofline_of(fmt_name, W, H, us_per_frame, mode, kernel):
+def roofline_of(fmt_name, W, H, us_per_frame, mode, kernel, valu_ns=None):
     alg = BYTES_PER_PX[fmt_name] * W * H
     ach = alg / (us_per_frame * 1e-6) / 1e9
     per_frame, src = pmc_traffic(fmt_name, W, H, mode)
-    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+    valu = valu_fields(fmt_name, W, H, us_per_frame, valu_ns) if kernel == "rd_develop_batch" else {}
+    return {"bound": bound_of(fmt_name, ach / HBM_PEAK_GBPS, valu) if valu else ("hbm" if fmt_name == "f32" else "valu"),
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), **valu,
             "traffic": int(per_frame) if per_frame is not None else None, "traffic_source": src,
             "traffic_unit": "HBM bytes per frame", "kernel": kernel, "algorithmic_bytes_per_frame": alg}
 
@@ -502,7 +549,7 @@ def extra_single_frame(torch, np, ra, dev, dev_index, cfa_t, p, stream, iters=60
 
 
 def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, ring_n, row_bands, steps, stream, label, kernel_mode,
-                tiled=False):
+                tiled=False, valu_ns=None):
     """A batch workload on another surface format / frame size, timed like the headline (HIP events, descriptors alternate).
     tiled: RD_BATCH_PERSISTENT=0 for this context -- every frame is `row_bands` separate row-band launches (BASELINE
     config 5's "tiled multi-launch per frame"); by default the multi-frame launch needs no bands of its own and ignores them."""
@@ -551,7 +598,7 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
             # what ran: the multi-frame launch sweeps a frame in row order and cuts no bands of its own
             "row_bands_effective": row_bands if lpc >= F * max(1, row_bands) else 1,
             "frames_per_launch": round(F / lpc, 3),
-            "roofline": roofline_of(fmt_name, W, H, us, kernel_mode, "rd_develop_quads" if lpc >= F else "rd_develop_batch"),
+            "roofline": roofline_of(fmt_name, W, H, us, kernel_mode, "rd_develop_quads" if lpc >= F else "rd_develop_batch", valu_ns),
             "verified": bool(ok), "verified_note": note}
 
 
@@ -646,7 +693,7 @@ def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
                      "PCIe-inclusive; RGB8 = JPEG feed (alpha strip fused), RGBA8 = PNG feed")
     return out
 
-def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream):
+def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None):
     out = {}
     t0 = time.perf_counter()
     out["single_frame_f32"] = extra_single_frame(torch, np, ra, dev, dev_index, cfas[0], params[0], stream)
@@ -655,14 +702,14 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream):
     n8 = len(cfas)
     out["batch_rgba8"] = extra_batch(torch, np, ra, dev, dev_index, "u8", cfas[:n8], params[:n8], 6016, 4016, 32, 1, 6, stream,
                                      f"the reference's own surface (Rgba8Unorm, pipeline.rs:322) on the batch workload: {n8} x 6016x4016, "
-                                     "randomised stacks, fused histogram, strict f32 arithmetic", "multi")
+                                     "randomised stacks, fused histogram, strict f32 arithmetic", "multi", valu_ns=valu_ns)
     W5, H5 = 11648, 8736
     c5, p5 = make_batch(torch, np, ra, dev, W5, H5, 16, 1 << 20, 1)
     out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 6, stream,
                                            "BASELINE configs[4] shape on one GPU: 16 x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
                                            "randomised stacks, fused histogram, strict f32 arithmetic; default launch mode: multi-frame "
                                            "launches (4 frames each, capped by the ring of 4), which sweep a frame in row order and "
-                                           "need no row bands of their own", "multi")
+                                           "need no row bands of their own", "multi", valu_ns=valu_ns)
     out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3, stream,
                                                  "the same 16 x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
                                                  "8 row-band launches per frame (RD_BATCH_PERSISTENT=0)", "per_frame", tiled=True)
@@ -754,6 +801,7 @@ def run_ranks(args):
         elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                         # HIP events on the launch stream
     elapsed_own = elapsed
+    valu_ns = measure_valu_ns(ra, dev_index) if (rank == 0 and not args.no_box) else None     # right after the region: the clocks are up
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -795,7 +843,7 @@ def run_ranks(args):
                          "one process per GPU (torch.distributed, backend " + (backend if world > 1 else "none: single rank") + ")" + unmeasured,
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
                          "steps alternate between two frame arrays (slider stacks of the two batch halves swapped): every step "
-                         "uploads its descriptors", box=box)
+                         "uploads its descriptors", box=box, valu_ns=valu_ns)
     if rank == 0:
         # as-nccl: the duplicate-device rule applies to this run (nccl always; RAWDEV_DIAG_ASSUME_NCCL=1 lets the gloo
         # rehearsal on a one-GPU box prove that the rule fires)
@@ -846,7 +894,7 @@ def run_ranks(args):
     if rank == 0 and world == 1 and not args.no_extra and (W, H) == (6016, 4016) and args.data == "uniform":
         del ring
         try:
-            result["extra_configs"] = extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream)
+            result["extra_configs"] = extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
         except Exception as e:  # noqa: BLE001  (never lose the headline line to an extra)
             result["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

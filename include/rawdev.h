@@ -34,7 +34,7 @@ extern "C" {
  * 3: no signature changed.  Host renders no longer serialise on the pipeline (each call takes a render lane; the mutex only
  * guards the uniforms) and a full-resolution render is band-pipelined (see rd_render_full_res_to_bytes); new entry points
  * rd_host_alloc / rd_host_free (page-locked render destinations), rd_measure_hbm (the box's own streaming ceilings),
- * rd_device_identity. */
+ * rd_measure_valu, rd_device_identity, rd_selftest_q8_lut (+ _codes), rd_q8_lut_table. */
 #define RD_ABI_VERSION 3
 
 typedef enum rd_status {
@@ -292,6 +292,15 @@ int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64
  * host-side oracle can be compared with them. */
 int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst);
 
+/* Round 4: the export kernel takes the 8-bit codes of the RGBA8 / RGB8 surfaces from a threshold table in LDS (the code is a
+ * monotone step function of x with at most one step per 2^16 float encodings).  rd_selftest_q8_lut
+ * runs that table against the pinned trunc(255 * gamma(x) + 0.5) over ALL 2^32 float encodings on `device` (must report 0
+ * mismatches); rd_selftest_q8_lut_codes returns its codes for a range of encodings (n a multiple of 256) for a host-side
+ * oracle; rd_q8_lut_table (no device needed) returns the table itself: 3969 words, returns the count or a negative status. */
+int rd_selftest_q8_lut(int device, uint64_t *mismatches, uint32_t *first_bad);
+int rd_selftest_q8_lut_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst);
+int rd_q8_lut_table(uint32_t *dst, size_t cap_words);
+
 /* The same for the RGBA-f16 surface's shortcut: the binary16 value (and the 8-bit code for the fused histogram) of every
  * float encoding against binary16(pinned gamma) / the pinned code.  *fallbacks = encodings in binary16's normal range
  * (gamma >= 2^-14) where the pinned evaluation decides the half; below that range it always does. */
@@ -322,6 +331,9 @@ int rd_host_free(int device, void *ptr);
  * median launch reported.  Any output may be NULL.  Allocates 2 x bytes of device memory for the call. */
 int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
                    double *memset_GBps);
+/* Measurement aid (bench.py's valu_issue_frac): nanoseconds one full-rate VALU wave-instruction (v_fma_f32, all VGPR) costs a
+ * SIMD of this device right now, eight waves per SIMD as the export kernel runs. */
+int rd_measure_valu(int device, double *ns_per_full_rate_instruction);
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);
 int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes);

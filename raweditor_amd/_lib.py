@@ -96,12 +96,16 @@ PROTOTYPES = {
     "rd_exporter_release": (_I, [_VP, _U32]),
     "rd_selftest_q8": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "rd_selftest_q8_codes": (_I, [_I, _U32, _U32, _VP]),
+    "rd_selftest_q8_lut": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32)]),
+    "rd_selftest_q8_lut_codes": (_I, [_I, _U32, _U32, _VP]),
+    "rd_q8_lut_table": (_I, [_VP, _SZ]),
     "rd_selftest_f16": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64)]),
     "rd_selftest_f16_halves": (_I, [_I, _U32, _U32, _VP]),
     "rd_ljpeg_decode": (_I, [_VP, _SZ, _VP, _SZ, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "rd_host_alloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_host_free": (_I, [_I, _VP]),
     "rd_measure_hbm": (_I, [_I, _SZ, _U32] + [C.POINTER(C.c_double)] * 4),
+    "rd_measure_valu": (_I, [_I, C.POINTER(C.c_double)]),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_device_free": (_I, [_I, _VP]),
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),

@@ -146,6 +146,22 @@ static int rd_check_device(int device, int *n_cu)
     return RD_OK;
 }
 
+// The 8-bit surfaces' threshold table (rd_kernels.h, rd_q8_lut_*): built once per process from the pinned gamma, copied into
+// each device's rd_q8_lut_dev the first time that device is used.  The device is current.
+static int rd_q8_lut_ensure(int device)
+{
+    static std::mutex mu;
+    static std::vector<uint32_t> table;
+    static bool done[64] = {};
+    if (device < 0 || device >= 64) return rd_fail(RD_ERR_NO_DEVICE, "device %d out of range", device);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[device]) return RD_OK;
+    if (table.empty()) { table.assign(RD_Q8_LUT_WORDS + 63u, 0u); rd_q8_lut_build(table.data()); }
+    RD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rd_q8_lut_dev), table.data(), table.size() * sizeof(uint32_t)));
+    done[device] = true;
+    return RD_OK;
+}
+
 static uint32_t rd_env_u32(const char *name, uint32_t dflt)
 {
     const char *s = getenv(name);
@@ -672,6 +688,8 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
 
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
     rd_pipeline *p = new (std::nothrow) rd_pipeline;
     if (!p) return rd_fail(RD_ERR_OOM, "host allocation failed");
     p->device = device;
@@ -1151,6 +1169,8 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (rc) return rc;
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
     rd_batch *b = new (std::nothrow) rd_batch;
     if (!b) return rd_fail(RD_ERR_OOM, "host allocation failed");
     b->device = device; b->w = w; b->h = h; b->fmt = fmt; b->hist = with_histogram != 0;
@@ -1732,6 +1752,8 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
     if (rc) return rc;
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
     rd_exporter *e = new (std::nothrow) rd_exporter;
     if (!e) return rd_fail(RD_ERR_OOM, "host allocation failed");
     e->device = device; e->w = w; e->h = h; e->fmt = fmt; e->math_mode = math_mode; e->n_slots = n_slots;
@@ -1859,6 +1881,72 @@ extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_
     if (fallbacks) *fallbacks = st.fallbacks;
     if (max_dist) *max_dist = rd_u2f(st.max_dist_bits);
     return RD_OK;
+}
+
+// The export kernel's threshold table (rd_q8_lut_bits) against the pinned evaluation, same sweep: the table in LDS, as there.
+__global__ void __launch_bounds__(256) rd_q8_lut_sweep(uint32_t base, rd_q8_stats *st, uint8_t *codes)
+{
+    __shared__ uint32_t lut[RD_Q8_LUT_WORDS];
+    rd_q8_lut_load(lut);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = rd_u2f(base + i);
+    const uint32_t sbits = rd_q8_lut_bits(x, lut);
+    const uint32_t fast = sbits >> 16;                           // bits 24..31 must be zero: compared as a whole
+    const uint32_t exact = rd_q8(rd_gamma_clamp(x));
+    if (codes) codes[i] = (uint8_t)fast;
+    if (!st) return;
+    if (fast != exact) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
+}
+
+extern "C" int rd_selftest_q8_lut(int device, uint64_t *mismatches, uint32_t *first_bad)
+{
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
+    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
+    RD_HIP(hipMalloc((void **)&dst, sizeof st));
+    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
+    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {    // 256 launches x 2^24 encodings
+        hipLaunchKernelGGL(rd_q8_lut_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint8_t *)nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_lut: %s", hipGetErrorString(e));
+    if (mismatches) *mismatches = st.mismatches;
+    if (first_bad) *first_bad = st.first_bad;
+    return RD_OK;
+}
+
+extern "C" int rd_selftest_q8_lut_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
+{
+    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
+        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_q8_lut_codes: n must be a non-zero multiple of 256 inside the 2^32 encodings");
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
+    uint8_t *dev = nullptr;
+    RD_HIP(hipMalloc((void **)&dev, n));
+    hipLaunchKernelGGL(rd_q8_lut_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(dst, dev, n, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_lut_codes: %s", hipGetErrorString(e));
+    return RD_OK;
+}
+
+// No device needed: the table itself (RD_Q8_LUT_WORDS words), for host-side checks of its construction.
+extern "C" int rd_q8_lut_table(uint32_t *dst, size_t cap_words)
+{
+    if (!dst || cap_words < RD_Q8_LUT_WORDS) return rd_fail(RD_ERR_INVALID_ARG, "rd_q8_lut_table: need room for %u words", RD_Q8_LUT_WORDS);
+    rd_q8_lut_build(dst);
+    return (int)RD_Q8_LUT_WORDS;
 }
 
 // The same for the binary16 surface's shortcut (rd_f16_gamma): halves and, with the histogram, codes.
@@ -2067,6 +2155,65 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
     if (fill_GBps) *fill_GBps = out[1];
     if (read_GBps) *read_GBps = out[2];
     if (memset_GBps) *memset_GBps = out[3];
+    return RD_OK;
+}
+
+// What one full-rate VALU wave-instruction costs a SIMD on THIS device right now: 512 x 1024 threads (8 waves per SIMD, as
+// the export kernel runs), eight independent v_fma_f32 chains per lane.  bench.py prices the export kernels' static
+// instruction budgets (profiles/isa_budget.json, in units of half a full-rate instruction) with it: valu_issue_frac.
+__global__ void __launch_bounds__(1024) rd_probe_valu(float *out, float a, float b, int iters)
+{
+    float av = a, bv = b, x[8];
+    asm volatile("" : "+v"(av), "+v"(bv));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (float)(threadIdx.x + i) * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(av), "v"(bv));
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    if (s == 1234.5678f) out[0] = s;
+}
+
+extern "C" int rd_measure_valu(int device, double *ns_per_full_rate_instruction)
+{
+    if (!ns_per_full_rate_instruction) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_valu: NULL argument");
+    int n_cu = 0;
+    int rc = rd_check_device(device, &n_cu);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    const int iters = 512, blocks = 2 * n_cu;                                   // two 1024-thread workgroups per CU
+    float *out = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&out, 64);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    std::vector<float> ms;
+    for (int r = 0; r < 6 && e == hipSuccess; ++r) {
+        e = hipEventRecord(e0, s);
+        hipLaunchKernelGGL(rd_probe_valu, dim3(blocks), dim3(1024), 0, s, out, 0.999f, 0.001f, iters);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float t = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (e == hipSuccess && r) ms.push_back(t);
+    }
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_measure_valu: %s", hipGetErrorString(e));
+    std::sort(ms.begin(), ms.end());
+    const double per_simd = (double)blocks * 16.0 * 8.0 * 4.0 * iters / ((double)n_cu * 4.0);     // wave-instructions each SIMD issued
+    *ns_per_full_rate_instruction = ms[ms.size() / 2] * 1e6 / per_simd;
     return RD_OK;
 }
 

@@ -357,6 +357,75 @@ __device__ __forceinline__ uint32_t rd_q8_gamma(float x)
     return rd_q8_gamma_bits(x, kc) & 0xffu;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the 8-bit code from a THRESHOLD TABLE in LDS (the export kernel's RGBA8 / RGB8 surfaces; RD_Q8_LUT=0 builds the
+// round-3 transcendental shortcut above instead, for A/B).
+//
+// q(x) = rd_q8(rd_gamma_clamp(x)) is a monotone step function of x with 255 steps (tools/q8_monotone.hip walks all 2^31
+// non-negative encodings in order: 0 decreases; the first step is at x = 1.105e-6, the last at 0.99569), and no 2^16
+// consecutive float encodings hold more than ONE step.  So the code is  base[bucket] + (x >= threshold[bucket])  with
+// bucket = the top 16 bits of the encoding -- and with three tricks the whole thing is three full-rate VALU instructions,
+// one shift-and-mask and one ds_read_b32 instead of v_log + v_mul + v_exp + 2 fma + sub + compare (28 -> ~10 issue cycles):
+//   * xc = clamp(x, 0, 1) (negative, NaN -> 0; the clamp is an output modifier of the instruction that produced x where
+//     the compiler can fold it, one v_med3_f32 otherwise), then w = xc * 2^-96: an exact power-of-two scaling that moves
+//     [2^-30, 1] onto the exponent fields 1 .. 31, so the top 16 bits of w ARE the table index 0 .. 0xF80 -- no lower clamp,
+//     no subtraction (everything below 2^-30 lands in the denormal buckets 0 .. 127, which all hold code 0);
+//   * an entry is E = (base << 16) + (0x10000 - t) - (bucket << 16), t = the threshold's offset inside the bucket (0x10000:
+//     no step): then s = E + bits(w) = (base << 16) + (0x10000 - t) + (low 16 bits of w) carries "low bits >= t" into bit 16
+//     by itself -- one v_add_u32, no compare, no select -- and bits 16..23 of s are the code (bits 24..31 are zero);
+//   * the pixel pack (v_perm_b32) and the histogram address take the code from byte 2 of s; it is never extracted.
+// The table (3969 words = 15.5 KiB) is built on the host from rd_gamma_clamp itself (rd_q8_lut_build: 255 bisections),
+// lives in a __device__ array and is copied into LDS when a workgroup starts: 24 KiB histogram + 15.5 KiB table leave two
+// workgroups per CU.  rd_selftest_q8_lut runs it against the pinned function for ALL 2^32 encodings on the device.
+// ---------------------------------------------------------------------------------------------
+#ifndef RD_Q8_LUT
+#define RD_Q8_LUT 1
+#endif
+#define RD_Q8_LUT_WORDS 3969u                /* buckets 0 .. 0xF80 (w = 2^-96: x = 1.0) */
+#define RD_Q8_LUT_SCALE 0x1p-96f             /* 0x0f800000 */
+#define RD_Q8_LUT_REBIAS 0x30000000u         /* bits(x) - bits(x * 2^-96) for normal results: 96 << 23 */
+
+__device__ uint32_t rd_q8_lut_dev[RD_Q8_LUT_WORDS + 63u];       // filled by the host before the first launch (rawdev.hip)
+
+// Host: the table from the pinned function.  thr[k-1] = the smallest encoding whose code is >= k (bisection: q is monotone).
+static inline void rd_q8_lut_build(uint32_t *lut /* RD_Q8_LUT_WORDS */)
+{
+    uint32_t thr[255];
+    for (uint32_t k = 1; k <= 255u; ++k) {
+        uint32_t lo = 0u, hi = 0x3f800000u;                  // q(lo) < k <= q(hi)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            const uint32_t q = (uint32_t)__builtin_fmaf(rd_gamma_clamp(rd_u2f(mid)), 255.0f, 0.5f);
+            if (q >= k) hi = mid; else lo = mid;
+        }
+        thr[k - 1u] = hi - RD_Q8_LUT_REBIAS;                 // as an encoding of w = x * 2^-96 (every threshold is far above 2^-30)
+    }
+    uint32_t k = 0;                                          // thresholds at or below the bucket start = the code there
+    for (uint32_t b = 0; b < RD_Q8_LUT_WORDS; ++b) {
+        const uint32_t start = b << 16, end = start + 0x10000u;
+        while (k < 255u && thr[k] <= start) ++k;
+        uint32_t t = 0x10000u;
+        if (k < 255u && thr[k] < end) t = thr[k] - start;    // at most one step per bucket (tools/q8_monotone.hip)
+        lut[b] = (k << 16) + (0x10000u - t) - start;
+    }
+}
+
+// s: the code of x in bits 16..23 (bits 24..31 zero, bits 0..15 a by-product).  `lut` is the LDS copy of the table.
+__device__ __forceinline__ uint32_t rd_q8_lut_bits(float x, const uint32_t *lut)
+{
+    const float xc = __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f);     // negative, NaN -> 0 (DX10_CLAMP / min3); > 1 -> 1
+    const uint32_t wb = rd_f2u(xc * RD_Q8_LUT_SCALE);
+    const uint32_t a = (uint32_t)((int32_t)wb >> 14) & 0x3ffcu;  // bucket * 4 (w >= 0: the arithmetic shift is the one measured at full rate)
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lut) + a) + wb;
+}
+
+// The export kernel copies the table into LDS once per workgroup.
+__device__ __forceinline__ void rd_q8_lut_load(uint32_t *lut)
+{
+    for (uint32_t i = threadIdx.x; i < RD_Q8_LUT_WORDS; i += blockDim.x) lut[i] = rd_q8_lut_dev[i];
+    __syncthreads();
+}
+
 // The same shortcut for the RGBA-f16 surface (BASELINE config 5): what leaves the kernel is the binary16 rounding of the
 // pinned gamma (and, with the fused histogram, its 8-bit code).  The hardware pow e = 2^z, z = log2(x) / 2.2, is within
 // (1.2 |z| + 2.25) * 2^-23 * e of the pinned value -- its error is that of z, which grows with |log2 x|
@@ -455,6 +524,32 @@ __device__ __forceinline__ void rd_hist_add_bits(uint32_t *lh, uint32_t hbase, u
     atomicAdd(reinterpret_cast<uint32_t *>(base + ((tr << RD_HIST_SHIFT) + hbase)), inc);
     atomicAdd(reinterpret_cast<uint32_t *>(base + ((tg << RD_HIST_SHIFT) + hbase)) + 256u * RD_HK, inc);
     atomicAdd(reinterpret_cast<uint32_t *>(base + ((tb << RD_HIST_SHIFT) + hbase)) + 512u * RD_HK, inc);
+}
+
+// The same for codes that sit in bits 16..23 of s (rd_q8_lut_bits; bits 24..31 zero, bits 0..15 arbitrary): the byte address
+// of bin q, copy c is ((s >> 16) << RD_HIST_SHIFT) + 4 c -- a full-rate shift and one v_lshl_add_u32 (6 issue cycles; the
+// add-magic encodings above need 4).  The empty asm keeps the shift a shift: left to itself hipcc fuses it into
+// v_bfe_u32 + v_lshl_or_b32, two VOP3 integer instructions that issue at half rate on this part (8 cycles;
+// tools/valu_probe2.hip, profiles/r04_valu_probe_lut.txt: v_lshrrev_b32 1.14 ns, v_bfe_u32 1.79 ns per wave-instruction).
+__device__ __forceinline__ uint32_t rd_sar16(uint32_t s)
+{
+    uint32_t c = s >> 16;
+    asm("" : "+v"(c));
+    return c;
+}
+__device__ __forceinline__ void rd_hist_add_b2(uint32_t *lh, uint32_t copy4, uint32_t sr, uint32_t sg, uint32_t sb, uint32_t inc)
+{
+    char *base = reinterpret_cast<char *>(lh);
+    atomicAdd(reinterpret_cast<uint32_t *>(base + ((rd_sar16(sr) << RD_HIST_SHIFT) + copy4)), inc);
+    atomicAdd(reinterpret_cast<uint32_t *>(base + ((rd_sar16(sg) << RD_HIST_SHIFT) + copy4)) + 256u * RD_HK, inc);
+    atomicAdd(reinterpret_cast<uint32_t *>(base + ((rd_sar16(sb) << RD_HIST_SHIFT) + copy4)) + 512u * RD_HK, inc);
+}
+
+template <bool ALPHA>
+__device__ __forceinline__ uint32_t rd_pack_rgba_b2(uint32_t sr, uint32_t sg, uint32_t sb)       // codes in byte 2 of each
+{
+    const uint32_t rg = __builtin_amdgcn_perm(sg, sr, 0x0c0c0602u);              // [r, g, 0, 0]
+    return __builtin_amdgcn_perm(sb, rg, ALPHA ? 0xff060100u : 0x0c060100u);     // [r, g, b, 0xff / 0]
 }
 
 // RGBA8 / RGB8 pixel from three such encodings: two byte permutes (v_perm_b32: selector bytes 0-3 pick the second operand's
@@ -632,17 +727,24 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         }
 #undef RD_PARK
     };
+#if defined(RD_COLOUR_HOOK_HEADER) || defined(RD_NO_Q8_SHORTCUT)
+    constexpr bool Q8LUT = false;
+#else
+    constexpr bool Q8LUT = (RD_Q8_LUT != 0) && (FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8);   // codes from the LDS threshold table
+#endif
     // lane constants of the gamma shortcuts (rd_kc), in VGPRs for the same reason; the asm keeps them there
     rd_kc kc = { 255.0f, RD_F16_KA / 64.0f, RD_F16_KB / 64.0f };
-    if constexpr (FMT != RD_FMT_RGBA_F32) {
+    if constexpr (FMT != RD_FMT_RGBA_F32 && !Q8LUT) {
         asm volatile("" : "+v"(kc.k255));
         if constexpr (FMT == RD_FMT_RGBA_F16) asm volatile("" : "+v"(kc.f16_ka), "+v"(kc.f16_kb));
     }
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
+    __shared__ uint32_t qlut[Q8LUT ? RD_Q8_LUT_WORDS : 1];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     __shared__ rd_f4 pf_dump[BURST ? 64 : 1];                    // where the LDS-DMA sweeps land (never read)
+    if constexpr (Q8LUT) rd_q8_lut_load(qlut);
     if (HIST) rd_hist_zero(lh);
     if constexpr (FMT == RD_FMT_RGBA_F32) {
         // The store stage holds [lane][c1, c2, c3] as RGBA; alpha is 1.0 for every pixel of every tile, so it is written
@@ -776,8 +878,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         rd_rgb c1 = { 0.0f, 0.0f, 0.0f }, c2 = c1, c3 = c1;
         const uint32_t hbase = rd_hist_base(copy);               // loop-invariant: hoisted
         auto count = [&](uint32_t qr, uint32_t qg, uint32_t qb, uint32_t inc) {      // one pixel's codes into the histogram
-            if constexpr (BITS) rd_hist_add_bits(lh, hbase, qr, qg, qb, inc);
+            if constexpr (Q8LUT) rd_hist_add_b2(lh, copy * 4u, qr, qg, qb, inc);
+            else if constexpr (BITS) rd_hist_add_bits(lh, hbase, qr, qg, qb, inc);
             else rd_hist_add(lh, copy, qr, qg, qb, inc);
+        };
+        auto code = [&](float v) -> uint32_t {                   // the 8-bit code of a linear value, as the surface's encoding of it
+            if constexpr (Q8LUT) return rd_q8_lut_bits(v, qlut);
+            else return rd_q8_gamma_bits(v, kc);
         };
         bool separable = false;                                  // wave-uniform
 #ifndef RD_COLOUR_HOOK_HEADER
@@ -790,8 +897,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             float v[5] = { C, A, D, B, A };
             rd_colour_separable<MATH>(u, v);
             if constexpr (Q8ONLY) {
-                q1r = rd_q8_gamma_bits(v[0], kc); q1g = rd_q8_gamma_bits(v[1], kc); q1b = rd_q8_gamma_bits(v[3], kc);
-                q2g = rd_q8_gamma_bits(v[2], kc); q2b = rd_q8_gamma_bits(v[4], kc);
+                q1r = code(v[0]); q1g = code(v[1]); q1b = code(v[3]);
+                q2g = code(v[2]); q2b = code(v[4]);
                 q2r = q1r; q3r = q1r; q3g = q2g; q3b = q1b;
                 if (HIST && valid) {
                     if (has_a) count(q1r, q1g, q1b, 2u);
@@ -821,9 +928,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         c1 = rd_rgb{ tr[0], tg[0], tb[0] }; c2 = rd_rgb{ tr[1], tg[1], tb[1] }; c3 = rd_rgb{ tr[2], tg[2], tb[2] };
 #endif
         if constexpr (Q8ONLY) {
-            q1r = rd_q8_gamma_bits(c1.r, kc); q1g = rd_q8_gamma_bits(c1.g, kc); q1b = rd_q8_gamma_bits(c1.b, kc);
-            q2r = rd_q8_gamma_bits(c2.r, kc); q2g = rd_q8_gamma_bits(c2.g, kc); q2b = rd_q8_gamma_bits(c2.b, kc);
-            q3r = rd_q8_gamma_bits(c3.r, kc); q3g = rd_q8_gamma_bits(c3.g, kc); q3b = rd_q8_gamma_bits(c3.b, kc);
+            q1r = code(c1.r); q1g = code(c1.g); q1b = code(c1.b);
+            q2r = code(c2.r); q2g = code(c2.g); q2b = code(c2.b);
+            q3r = code(c3.r); q3g = code(c3.g); q3b = code(c3.b);
         } else if constexpr (H16) {                               // triple by triple: halves packed and codes counted at once,
             float er, eg, eb;                                     // so that at most one triple's values are live
             er = rd_f16_gamma_value<HIST>(c1.r, kc, q1r); eg = rd_f16_gamma_value<HIST>(c1.g, kc, q1g); eb = rd_f16_gamma_value<HIST>(c1.b, kc, q1b);
@@ -874,6 +981,10 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             r.a0 = rd_pack_h2(c1.r, c1.g); r.a1 = rd_pack_h2(c1.b, 1.0f);
             r.b0 = rd_pack_h2(c2.r, c2.g); r.b1 = rd_pack_h2(c2.b, 1.0f);
             r.c0 = rd_pack_h2(c3.r, c3.g); r.c1 = rd_pack_h2(c3.b, 1.0f);
+        } else if constexpr (Q8LUT) {                            // RGBA8 / RGB8 from byte 2 of the table sums: two byte permutes per pixel
+            r.v1 = rd_pack_rgba_b2<FMT == RD_FMT_RGBA_U8>(q1r, q1g, q1b);
+            r.v2 = rd_pack_rgba_b2<FMT == RD_FMT_RGBA_U8>(q2r, q2g, q2b);
+            r.v3 = rd_pack_rgba_b2<FMT == RD_FMT_RGBA_U8>(q3r, q3g, q3b);
         } else if constexpr (BITS) {                             // RGBA8 / RGB8 from the encodings: two byte permutes per pixel
             r.v1 = rd_pack_rgba_bits<FMT == RD_FMT_RGBA_U8>(q1r, q1g, q1b);
             r.v2 = rd_pack_rgba_bits<FMT == RD_FMT_RGBA_U8>(q2r, q2g, q2b);

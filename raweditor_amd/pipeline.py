@@ -86,6 +86,13 @@ def measure_hbm(device: int = 0, nbytes: int = 1 << 30, reps: int = 5):
     return tuple(x.value for x in v)
 
 
+def measure_valu(device: int = 0) -> float:
+    """Nanoseconds one full-rate VALU wave-instruction costs a SIMD of this device right now (rd_measure_valu)."""
+    v = C.c_double()
+    check(_lib.lib().rd_measure_valu(int(device), C.byref(v)))
+    return v.value
+
+
 class RenderPipeline:
     """Owns one CFA plane in HBM plus the current uniforms (EditParams, wb, matrix, zoom/pan)."""
 

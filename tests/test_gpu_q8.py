@@ -13,10 +13,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _codes(ra, first, n):
+def _codes(ra, first, n, lut=False):
     from raweditor_amd import _lib
     out = np.empty(n, np.uint8)
-    _lib.check(_lib.lib().rd_selftest_q8_codes(0, first, n, out.ctypes.data_as(C.c_void_p)))
+    fn = _lib.lib().rd_selftest_q8_lut_codes if lut else _lib.lib().rd_selftest_q8_codes
+    _lib.check(fn(0, first, n, out.ctypes.data_as(C.c_void_p)))
     return out
 
 
@@ -40,7 +41,17 @@ def test_q8_shortcut_equals_the_pinned_codes_for_every_float(gpu_lib):
     assert 0 < fb.value < 2**31 * 0.01               # the pinned evaluation is the rare path
 
 
-def test_q8_shortcut_against_the_oracle(gpu_lib, refc):
+def test_q8_threshold_table_equals_the_pinned_codes_for_every_float(gpu_lib):
+    """Round 4: the export kernel's RGBA8 / RGB8 codes come from a threshold table in LDS (rd_q8_lut_bits): for ALL 2^32 float
+    encodings -- negative, NaN, denormal, > 1 included -- the table's code is trunc(255 * rd_gamma_clamp(x) + 0.5)."""
+    from raweditor_amd import _lib
+    bad, first = C.c_uint64(), C.c_uint32()
+    _lib.check(_lib.lib().rd_selftest_q8_lut(0, C.byref(bad), C.byref(first)))
+    assert bad.value == 0, f"{bad.value} encodings differ, first 0x{first.value:08x}"
+
+
+@pytest.mark.parametrize("lut", [False, True], ids=["transcendental-shortcut", "threshold-table"])
+def test_q8_shortcut_against_the_oracle(gpu_lib, refc, lut):
     ra = gpu_lib
     # where the oracle's code changes: bisect each of the 255 steps over the non-negative encodings
     L = refc.lib()
@@ -60,18 +71,18 @@ def test_q8_shortcut_against_the_oracle(gpu_lib, refc):
                 lo = mid
         first = (max(hi - 512, 0) // 256) * 256
         bits = np.arange(first, first + 1024, dtype=np.uint32)
-        assert np.array_equal(_codes(ra, first, 1024), _oracle_codes(refc, bits)), f"step to code {k} near 0x{hi:08x}"
+        assert np.array_equal(_codes(ra, first, 1024, lut), _oracle_codes(refc, bits)), f"step to code {k} near 0x{hi:08x}"
         checked += 1024
     # specials and a stride through every exponent, both signs
     for first in (0x00000000, 0x007fff00, 0x00800000, 0x3f7fff00, 0x3f800000, 0x7f7fff00, 0x7f800000, 0x7fc00000,
                   0x80000000, 0xbf800000, 0xff800000, 0xffffff00):
         bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
-        assert np.array_equal(_codes(ra, first, 256), _oracle_codes(refc, bits)), hex(first)
+        assert np.array_equal(_codes(ra, first, 256, lut), _oracle_codes(refc, bits)), hex(first)
     rng = np.random.default_rng(8)
     for first in rng.integers(0, 2**32 - 256, 64, dtype=np.uint64):
         first = int(first) // 256 * 256
         bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
-        assert np.array_equal(_codes(ra, first, 256), _oracle_codes(refc, bits)), hex(first)
+        assert np.array_equal(_codes(ra, first, 256, lut), _oracle_codes(refc, bits)), hex(first)
     assert checked == 255 * 1024
 
 

@@ -195,8 +195,11 @@ def test_narrow_surface_instruction_budget():
     """The RGBA8 and RGBA-f16 export kernels are bound by VALU issue ('Instruction budget'), so their
     per-tile instruction count is a property worth guarding like the register budget: tools/isa_budget.py compiles the kernel
     with the bench workload's path pinned, reads hipcc's own assembly and prices the main loop.  Round 3's figures: RGBA8
-    343 VALU / 862 issue cycles per tile (round 2: 397 / 1124), f16 408 / 1030 (488 / 1404).  No half-rate conversion
-    (v_cvt_u32_f32, v_fract_f32) and no v_cndmask may come back into the hot path of the RGBA8 gamma shortcut."""
+    343 VALU / 862 issue cycles per tile (round 2: 397 / 1124), f16 408 / 1030 (488 / 1404).  Round 4: the RGBA8 codes come
+    from the LDS threshold table -- 324 VALU / 698 cycles, NO transcendental left in its hot path, nine table reads, and the
+    half-rate forms hipcc likes to pick around it (v_bfe_u32, v_cndmask, conversions) must stay out.  The committed
+    profiles/isa_budget.json (what bench.py's valu_issue_frac is computed from) must be what the sources compile to."""
+    import json
     import os
     import re
     import subprocess
@@ -209,12 +212,13 @@ def test_narrow_surface_instruction_budget():
         import pytest
         pytest.skip("hipcc not found")
     import tempfile
+    committed = json.load(open(os.path.join(root, "profiles", "isa_budget.json")))["kernels"]
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "rawdev.s")
         subprocess.run([hipcc] + isa_budget.FLAGS + ["-DRD_BUDGET_ELIDE=128u", "-o", asm, isa_budget.SRC], check=True,
                        stderr=subprocess.DEVNULL)
-        limits = {"<2,true,true,0,false>": (360, 900), "<1,true,true,0,false>": (420, 1060)}
-        for kernel, (max_valu, max_cycles) in limits.items():
+        limits = {"<2,true,true,0,false>": ("u8", 335, 720, 0), "<1,true,true,0,false>": ("f16", 420, 1060, 18)}
+        for kernel, (surface, max_valu, max_cycles, n_quarter) in limits.items():
             listing = os.path.join(td, "loop.txt")
             out = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_budget.py"), "--asm", asm, "--kernel", kernel,
                                   "--listing", listing], capture_output=True, text=True, check=True).stdout
@@ -222,13 +226,17 @@ def test_narrow_surface_instruction_budget():
             assert m, out
             valu, full, half, sgpr, quarter, cycles = map(int, m.groups())
             assert valu <= max_valu and cycles <= max_cycles, (kernel, valu, cycles)
-            assert quarter == 18, (kernel, quarter)                          # nine v_log_f32 + nine v_exp_f32, nothing else
+            assert quarter == n_quarter, (kernel, quarter)
+            assert (committed[surface]["valu_instructions"], committed[surface]["issue_cycles"]) == (valu, cycles), \
+                f"profiles/isa_budget.json is stale for {surface}: rerun tools/isa_budget.py --json (see profiles/README.md)"
             hot = [ln for ln in open(listing) if not ln.startswith("C")]
-            assert sum("v_exp_f32" in ln and "clamp" in ln for ln in hot) == 9, kernel     # the clamp rides on v_exp_f32
             if kernel.startswith("<2"):
-                assert not any(re.search(r"v_cvt_u32_f32|v_fract_f32|v_cndmask", ln) for ln in hot), kernel
+                assert not any(re.search(r"v_exp_f32|v_log_f32|v_cvt_u32_f32|v_fract_f32|v_cndmask|v_bfe_u32|v_med3_f32", ln) for ln in hot), kernel
+                assert sum("ds_read_b32" in ln for ln in hot) == 9, kernel                 # one table read per value
+                assert sum("v_add_f32" in ln and "clamp" in ln for ln in hot) == 9, kernel  # the [0, 1] clamp rides on the stack's last add
                 assert sum("v_perm_b32" in ln for ln in hot) == 6, kernel                  # two byte permutes per pixel
             else:
+                assert sum("v_exp_f32" in ln and "clamp" in ln for ln in hot) == 9, kernel  # the clamp rides on v_exp_f32
                 assert sum("v_cvt_pk_f16_f32" in ln for ln in hot) == 6, kernel            # two packed conversions per pixel
 
 
@@ -346,3 +354,48 @@ def test_q8_pack_by_fma_is_the_pinned_pack_for_every_float_in_0_1(tmp_path):
                    check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, check=True).stdout
     assert out.startswith("mismatches 0 "), out
+
+
+def test_q8_threshold_table_construction_against_the_oracle(refc):
+    """rd_q8_lut_table (no device): the export kernel's threshold table for the 8-bit code (rd_kernels.h, round 4), built on
+    the host from the pinned gamma.  Evaluated here in plain integer arithmetic the way the kernel does --
+    s = E[bits(w) >> 16] + bits(w), code = s >> 16, w = x * 2^-96 -- at every bucket's first and last encoding and on both
+    sides of every step, it must give the ORACLE's pow -> clamp -> pack code; there are exactly 255 steps, at most one per
+    bucket, and the codes never decrease."""
+    import ctypes as C
+    import numpy as np
+    from raweditor_amd import _lib
+    n = 3969
+    tab = np.zeros(n, np.uint32)
+    assert _lib.lib().rd_q8_lut_table(tab.ctypes.data_as(C.c_void_p), n) == n
+    assert _lib.lib().rd_q8_lut_table(tab.ctypes.data_as(C.c_void_p), n - 1) < 0
+    L = refc.lib()
+
+    def oracle_code(xbits):
+        x = np.array([xbits], np.uint32).view(np.float32)[0]
+        g = L.ref_powf(C.c_float(x), C.c_float(np.float32(0.45454547)), 0)
+        g = np.float32(min(max(g, 0.0), 1.0)) if g == g else np.float32(0)
+        return int(refc.pack_u8(np.array([g], np.float32))[0])
+
+    def table_code(wbits):
+        s = (int(tab[wbits >> 16]) + wbits) & 0xffffffff
+        assert s >> 24 == 0, hex(wbits)                        # the kernel relies on bits 24..31 being zero
+        return s >> 16
+
+    rebias = 96 << 23
+    steps, prev = 0, 0
+    for b in range(128, n):                                     # buckets 0..127 are the denormal results: code 0
+        start = b << 16
+        last = start + 0xffff if b < n - 1 else start          # the top bucket holds w = 2^-96 (x = 1.0) only
+        t = 0x10000 - ((int(tab[b]) + start) & 0xffff) if (int(tab[b]) + start) & 0xffff else 0x10000
+        probes = {start, last}
+        if t < 0x10000:
+            probes |= {start + t - 1, start + t}
+            steps += 1
+        for w in sorted(probes):
+            c = table_code(w)
+            assert c == oracle_code(w + rebias), (hex(w), c)
+            assert c >= prev
+            prev = c
+    assert steps == 255 and prev == 255
+    assert all(table_code(b << 16 | 0xffff) == 0 for b in range(0, 128))

@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--listing", help="write the annotated main-loop listing here")
     ap.add_argument("--summary", help="write the per-stage table here (also printed)")
     ap.add_argument("--define", action="append", default=[], help="extra -D for the compile (A/B builds)")
+    ap.add_argument("--json", help="merge this kernel's hot-path totals into this JSON file (profiles/isa_budget.json: what bench.py's "
+                                   "valu_issue_frac is computed from)")
     args = ap.parse_args()
 
     if args.asm:
@@ -309,6 +311,23 @@ def main():
                f"(static count: a wave-uniform branch not taken, e.g. an elided step, costs less)")
     text = "\n".join(out)
     print(text)
+    if args.json:
+        import json
+        try:
+            doc = json.load(open(args.json))
+        except (OSError, ValueError):
+            doc = {}
+        surface = {"0": "f32", "1": "f16", "2": "u8", "3": "rgb8"}.get(args.kernel.strip("<>").split(",")[0].strip(), args.kernel)
+        doc.setdefault("note", "tools/isa_budget.py --json: hot-path VALU of rd_develop_batch's main loop per TILE (one wave, 64 quads = 256 px), "
+                               "static count from hipcc's assembly with the bench workload's elision flags pinned (-DRD_BUDGET_ELIDE=128u); "
+                               "issue_cycles prices full-rate instructions at 2, half-rate at 4, quarter-rate at 8 (tools/valu_probe2.hip)")
+        doc.setdefault("kernels", {})[surface] = {
+            "kernel": "rd_develop_batch" + args.kernel, "defines": args.define, "valu_instructions": tot["valu"], "full_rate": tot["full"],
+            "half_rate": tot["half"], "quarter_rate": tot["quarter"], "issue_cycles": tot["cyc"], "lds_instructions": tot["LDS"],
+            "salu_instructions": tot["SALU"], "px_per_tile": 256}
+        with open(args.json, "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
+            f.write("\n")
     if args.summary:
         open(args.summary, "w").write(text + "\n")
     if args.listing:

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // KIND: 0 fma v,v,v   1 fma s,v,v (one SGPR)   2 fmaak (literal addend)   3 fma v,v,1.0 (inline const)
@@ -72,6 +73,15 @@ __global__ void __launch_bounds__(1024) k(float *out, float a, float b, int iter
                 if (KIND == 45) asm volatile("v_sub_u32_sdwa %0, %0, %1 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(v) : "v"(bv));
                 if (KIND == 46) asm volatile("v_cmp_gt_u32_e32 vcc, %1, %0" : : "v"(v), "v"(bv) : "vcc");
                 if (KIND == 47) asm volatile("v_cvt_f16_f32_e32 %0, %0" : "+v"(v));
+                // round 4: the shifts / field extracts around the LDS threshold table (rd_q8_lut_bits, rd_hist_add_b2)
+                if (KIND == 55) asm volatile("v_lshrrev_b32_e32 %0, 14, %0" : "+v"(v));
+                if (KIND == 56) asm volatile("v_bfe_u32 %0, %0, 16, 8" : "+v"(v));
+                if (KIND == 57) asm volatile("v_lshl_or_b32 %0, %0, 5, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 58) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 59) asm volatile("v_ashrrev_i32_e32 %0, 16, %0\n\ts_nop 0" : "+v"(v));
+                if (KIND == 60) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(v));
+                if (KIND == 61) asm volatile("v_lshrrev_b32_e32 %0, 16, %0\n\tv_lshl_add_u32 %0, %0, 5, %1" : "+v"(v) : "v"(bv));
+                if (KIND == 62) asm volatile("v_mul_f32_e32 %0, 0x0f800000, %0" : "+v"(v));
                 // packed f32 (two lane-ops per instruction): plain, with op_sel broadcasts, with an inline constant
                 if (KIND >= 48 && KIND <= 54) {
                     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -104,15 +114,18 @@ static void run(const char *name, float *out)
     for (int r = 0; r < 4; ++r) hipLaunchKernelGGL((k<KIND, ILP>), dim3(blocks), dim3(1024), 0, 0, out, 0.999f, 0.001f, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 4;
-    const double instr = (double)blocks * 16 * ILP * 4 * iters * (KIND == 13 ? 2 : KIND == 43 ? 4 : 1);     // wave-instructions
+    const double instr = (double)blocks * 16 * ILP * 4 * iters * (KIND == 13 || KIND == 61 ? 2 : KIND == 43 ? 4 : 1);     // wave-instructions (s_nop not counted)
     printf("%-40s ILP %2d: %8.1f us  %6.2f ns per wave-instr per SIMD  (%5.2f T lane-op/s)\n", name, ILP, ms * 1e3,
            ms * 1e6 / (instr / 1024), instr * 64 / (ms * 1e-3) / 1e12);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     float *out; CK(hipMalloc((void **)&out, 64));
 #define R(K, N) run<K, 8>(N, out); run<K, 2>(N, out)
+    R(26, "v_ashrrev_i32"); R(55, "v_lshrrev_b32 14"); R(60, "v_lshlrev_b32 1"); R(56, "v_bfe_u32"); R(57, "v_lshl_or_b32"); R(58, "v_add_u32 v,v");
+    R(59, "v_ashrrev_i32 + s_nop 0 (per v instr)"); R(61, "v_lshrrev_b32 + v_lshl_add_u32 (per instr, 2)"); R(62, "v_mul_f32 literal 2^-96 (denormal results)");
+    if (argc > 1 && !strcmp(argv[1], "new")) return 0;
     R(0, "v_fma_f32 v,v,v"); R(1, "v_fma_f32 s,v,v"); R(2, "v_fmaak_f32 v,v,literal"); R(14, "v_fmamk_f32 v,literal,v");
     R(3, "v_fma_f32 v,v,1.0 (inline)"); R(10, "v_fma_f32 v,s,s");
     R(9, "v_fmac_f32_e32 v,v"); R(4, "v_mul_f32_e32 v,v"); R(5, "v_mul_f32_e32 s,v"); R(6, "v_mul_f32_e32 literal,v");
