@@ -6,7 +6,7 @@
 // pinned 255 * gamma(x) over every encoding, and how many encodings take the pinned evaluation.
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Ioracle -o tools/q8_exhaustive \
 //         tools/q8_exhaustive.hip -Loracle -ldevelop_ref -Wl,-rpath,\$ORIGIN/../oracle -pthread
-//   tools/q8_exhaustive [--device-only]
+//   tools/q8_exhaustive [--device-only] [--lut]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -47,6 +47,22 @@ __global__ void __launch_bounds__(256) k(uint32_t base, uint8_t *out8, q8_stats 
     }
 }
 
+// round 4: the export kernel's LDS threshold table (rd_q8_lut_bits) instead of the transcendental shortcut: --lut
+__global__ void __launch_bounds__(256) k_lut(uint32_t base, uint8_t *out8, q8_stats *st)
+{
+    __shared__ uint32_t lut[RD_Q8_LUT_WORDS];
+    rd_q8_lut_load(lut);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = rd_u2f(base + i);
+    const uint32_t fast = rd_q8_lut_bits(x, lut) >> 16;
+    const uint32_t exact = rd_q8(rd_gamma_clamp(x));
+    out8[i] = (uint8_t)fast;
+    if (fast != exact) {
+        atomicAdd(&st->mismatches, 1ull);
+        atomicMin(&st->first_bad, base + i);
+    }
+}
+
 static uint8_t oracle_q8(uint32_t bits)
 {
     float x; memcpy(&x, &bits, 4);
@@ -60,7 +76,13 @@ static uint8_t oracle_q8(uint32_t bits)
 
 int main(int argc, char **argv)
 {
-    const bool device_only = argc > 1 && !strcmp(argv[1], "--device-only");
+    bool device_only = false, lut = false;
+    for (int a = 1; a < argc; ++a) { device_only |= !strcmp(argv[a], "--device-only"); lut |= !strcmp(argv[a], "--lut"); }
+    if (lut) {
+        std::vector<uint32_t> table(RD_Q8_LUT_WORDS + 63u, 0u);
+        rd_q8_lut_build(table.data());
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(rd_q8_lut_dev), table.data(), table.size() * sizeof(uint32_t)));
+    }
     const uint32_t CH = 1u << 26;
     uint8_t *dev; CK(hipMalloc((void **)&dev, (size_t)CH));
     q8_stats *dst; CK(hipMalloc((void **)&dst, sizeof(q8_stats)));
@@ -72,7 +94,8 @@ int main(int argc, char **argv)
     std::atomic<uint32_t> first_bad{ 0xffffffffu };
     for (uint32_t c = 0; c < 64; ++c) {
         const uint32_t base = c * CH;
-        hipLaunchKernelGGL(k, dim3(CH / 256), dim3(256), 0, 0, base, dev, dst);
+        if (lut) hipLaunchKernelGGL(k_lut, dim3(CH / 256), dim3(256), 0, 0, base, dev, dst);
+        else hipLaunchKernelGGL(k, dim3(CH / 256), dim3(256), 0, 0, base, dev, dst);
         CK(hipGetLastError());
         CK(hipMemcpy(host.data(), dev, (size_t)CH, hipMemcpyDeviceToHost));
         if (!device_only) {
@@ -93,16 +116,17 @@ int main(int argc, char **argv)
         if (c % 16 == 15) { printf("checked %u / 64 chunks\n", c + 1); fflush(stdout); }
     }
     CK(hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost));
-    printf("RD_Q8_EPS = %g codes\n", (double)RD_Q8_EPS);
-    printf("rd_q8_gamma vs rd_q8(rd_gamma_clamp) on the device, all 2^32 encodings: %llu mismatches", st.mismatches);
+    const char *what = lut ? "rd_q8_lut_bits (LDS threshold table)" : "rd_q8_gamma";
+    if (!lut) printf("RD_Q8_EPS = %g codes\n", (double)RD_Q8_EPS);
+    printf("%s vs rd_q8(rd_gamma_clamp) on the device, all 2^32 encodings: %llu mismatches", what, st.mismatches);
     if (st.mismatches) printf(" (first at 0x%08x)", st.first_bad);
     printf("\n");
     if (!device_only) {
-        printf("rd_q8_gamma vs the oracle's pow + clamp + pack on the host, all 2^32 encodings: %llu mismatches", (unsigned long long)bad);
+        printf("%s vs the oracle's pow + clamp + pack on the host, all 2^32 encodings: %llu mismatches", what, (unsigned long long)bad);
         if (bad) printf(" (first at 0x%08x)", first_bad.load());
         printf("\n");
     }
-    printf("largest |y' - y| over all x >= FLT_MIN: %.6g codes; encodings that take the pinned evaluation: %llu of 2^31 non-negative "
+    if (!lut) printf("largest |y' - y| over all x >= FLT_MIN: %.6g codes; encodings that take the pinned evaluation: %llu of 2^31 non-negative "
            "(%.4f %%)\n", (double)st.max_dist, st.fallbacks, 100.0 * (double)st.fallbacks / 2147483648.0);
     return (st.mismatches || bad) ? 1 : 0;
 }
