@@ -107,6 +107,31 @@ inline bool is_identity_matrix(const std::array<float, 9> &m)
 
 using Histogram = std::array<std::array<uint32_t, 256>, 3>;
 
+// Page-locked host bytes (rd_host_alloc): a render destination the GPU's DMA engine writes directly -- what
+// export_image_async (main.rs:1749-1754) would hold instead of a fresh Vec<u8> to make a 24 MP export cost the PCIe
+// transfer and nothing else (include/rawdev.h, rd_render_full_res_to_bytes).  Move-only.
+class PinnedBytes {
+public:
+    explicit PinnedBytes(size_t bytes, int device = 0) : device_(device), bytes_(bytes)
+    {
+        void *p = nullptr;
+        check(rd_host_alloc(device, bytes, &p));
+        p_ = static_cast<uint8_t *>(p);
+    }
+    PinnedBytes(PinnedBytes &&o) noexcept : device_(o.device_), bytes_(o.bytes_), p_(o.p_) { o.p_ = nullptr; }
+    PinnedBytes(const PinnedBytes &) = delete;
+    PinnedBytes &operator=(const PinnedBytes &) = delete;
+    ~PinnedBytes() { if (p_) rd_host_free(device_, p_); }
+    uint8_t *data() { return p_; }
+    const uint8_t *data() const { return p_; }
+    size_t size() const { return bytes_; }
+
+private:
+    int device_;
+    size_t bytes_;
+    uint8_t *p_ = nullptr;
+};
+
 // gpu::RenderPipeline.  Move-only owner of an rd_pipeline; share it across threads by reference or
 // shared_ptr exactly like the reference shares Arc<RenderPipeline> (main.rs:1054, :1749).
 class RenderPipeline {
@@ -168,6 +193,8 @@ public:
         check(rd_render_full_res_to_bytes(h_, v.data(), v.size()));
         return v;
     }
+    // The same render into memory the caller keeps: a reused buffer (no first-touch page faults) or PinnedBytes (direct DMA).
+    void render_full_res_into(uint8_t *dst, size_t len) const { check(rd_render_full_res_to_bytes(h_, dst, len)); }
     std::vector<uint8_t> render_to_histogram_bytes() const                                              // :615
     {
         std::vector<uint8_t> v((size_t)histogram_width * histogram_height * 4);

@@ -124,6 +124,18 @@ static void test_pipeline_gpu()
     const std::vector<uint8_t> here = pipe.render_full_res_to_bytes();
     t.join();
     EXPECT(from_thread == exp8 && here == exp8);
+
+    // the export into memory the caller keeps: page-locked (the DMA engine writes it) and an ordinary reused buffer
+    rawdev::PinnedBytes pin(exp8.size());
+    std::memset(pin.data(), 0x5a, pin.size());
+    pipe.render_full_res_into(pin.data(), pin.size());
+    EXPECT(std::memcmp(pin.data(), exp8.data(), exp8.size()) == 0);
+    std::vector<uint8_t> mine(exp8.size(), 0xa5);
+    pipe.render_full_res_into(mine.data(), mine.size());
+    EXPECT(mine == exp8);
+    bool threw = false;
+    try { pipe.render_full_res_into(mine.data(), mine.size() - 4); } catch (const rawdev::Error &) { threw = true; }
+    EXPECT(threw);
 }
 
 // The node-level batch entry through the C++ mirror: 5 frames on one device, surfaces and u64 histogram against the oracle.
