@@ -142,6 +142,25 @@ def self_launch(world, argv, script=None):
 
 
 # ------------------------------------------------------------------------------------------------
+class quiet_gc:
+    """No cyclic-GC pass inside a timed region: a generation-2 collection of a process that has torch imported takes
+    20-30 ms (measured: one `--host node` step in ~13 took 40 ms instead of 20 -- the collection happened to fall into it;
+    with one process per GPU the same pause hides behind queued work).  Collect before, disable inside, restore after."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 def usable_cores():
     """Threads worth starting: the CPUs this process may run on, capped by the cgroup's CPU quota (a GPU box gives a
     one-GPU job a share of the host -- 256 hardware threads are visible, far fewer can run at once)."""
@@ -787,7 +806,7 @@ def run_ranks(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.cuda.stream(stream):
+    with torch.cuda.stream(stream), quiet_gc():
         for _ in range(args.warmup):
             step()
         barrier()
@@ -894,7 +913,8 @@ def run_ranks(args):
     if rank == 0 and world == 1 and not args.no_extra and (W, H) == (6016, 4016) and args.data == "uniform":
         del ring
         try:
-            result["extra_configs"] = extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
+            with quiet_gc():                               # host-timed medians in there
+                result["extra_configs"] = extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
         except Exception as e:  # noqa: BLE001  (never lose the headline line to an extra)
             result["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -978,13 +998,17 @@ def run_node(args):
     nb.synchronize()
     s0 = torch.cuda.ExternalStream(nb.stream(0), device=torch.device("cuda", devices[0]))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(s0)
-    for _ in range(args.steps):
-        step()
-    ev1.record(s0)
-    nb.synchronize()
-    elapsed = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        ev0.record(s0)
+        step_ms = []
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            step()
+            step_ms.append((time.perf_counter() - t1) * 1e3)   # with a histogram every step ends synchronised: its own wall time
+        ev1.record(s0)
+        nb.synchronize()
+        elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                         # HIP events on device 0's launch stream
 
     if with_hist:
@@ -1008,6 +1032,10 @@ def run_node(args):
     result["devices"] = [{"slot": i, "device_index": d, "pci_bus_id": idents[i].get("pci_bus_id"), "name": idents[i].get("name"),
                           "launches": nb.last_launch_count(i) * args.steps} for i, d in enumerate(devices)]
     result["distinct_devices"] = len({(i.get("pci_bus_id") or f"index:{d}") for i, d in zip(idents, devices)})
+    if with_hist:
+        result["step_ms"] = {"min": round(min(step_ms), 4), "median": round(sorted(step_ms)[len(step_ms) // 2], 4), "max": round(max(step_ms), 4),
+                             "all": [round(x, 3) for x in step_ms] if len(step_ms) <= 32 else None,
+                             "note": "host wall time of each step (develop + histogram, which synchronises)"}
     result["env"] = {k: os.environ.get(k) for k in DIAG_ENV + ("RD_NODE_REDUCE", "RAWDEV_RCCL_LIB")}
     if with_hist:
         # the histogram call on its own (per-device fold + all-reduce over RCCL when N > 1 + read-back + synchronise), idle devices

@@ -74,15 +74,10 @@ extern "C" int rd_device_identity(int device, char *pci_bus_id, size_t pci_cap, 
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return rd_fail(RD_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n) return rd_fail(RD_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
-    if (pci_bus_id && pci_cap) {
-        pci_bus_id[0] = 0;
-        RD_HIP(hipDeviceGetPCIBusId(pci_bus_id, (int)pci_cap, device));
-    }
-    if (name && name_cap) {
-        hipDeviceProp_t prop;
-        RD_HIP(hipGetDeviceProperties(&prop, device));
-        snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
-    }
+    hipDeviceProp_t prop;
+    RD_HIP(hipGetDeviceProperties(&prop, device));
+    if (pci_bus_id && pci_cap) snprintf(pci_bus_id, pci_cap, "%04x:%02x:%02x.0", prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
     return RD_OK;
 }
 
