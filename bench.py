@@ -400,7 +400,9 @@ def valu_fields(fmt_name, W, H, us_per_frame, valu_ns, n_simd=1024):
             "valu_issue_cycles_per_tile": b["issue_cycles"], "valu_instructions_per_tile": b["valu_instructions"],
             "valu_ns_per_full_rate_instruction": round(valu_ns, 4), "valu_effective_GHz": round(2.0 / valu_ns, 3),
             "valu_source": f"profiles/isa_budget.json [{b['kernel']}] (static count from hipcc's assembly, bench workload's path) priced with "
-                           "rd_measure_valu of this run; static issue bound: stalls, LDS and memory waits come on top"}
+                           "rd_measure_valu of this run (a v_mul / v_add loop at full occupancy, right after the timed region); a static "
+                           "issue bound: stalls, LDS and memory waits come on top, and the part may clock a memory-bound kernel higher "
+                           "than the calibration loop, so for the f32 surface the fraction is an upper estimate"}
 
 
 def bound_of(fmt_name, hbm_frac, valu):

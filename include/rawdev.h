@@ -331,8 +331,8 @@ int rd_host_free(int device, void *ptr);
  * median launch reported.  Any output may be NULL.  Allocates 2 x bytes of device memory for the call. */
 int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
                    double *memset_GBps);
-/* Measurement aid (bench.py's valu_issue_frac): nanoseconds one full-rate VALU wave-instruction (v_fma_f32, all VGPR) costs a
- * SIMD of this device right now, eight waves per SIMD as the export kernel runs. */
+/* Measurement aid (bench.py's valu_issue_frac): nanoseconds one full-rate VALU wave-instruction (v_mul_f32 / v_add_f32, all
+ * VGPR: the colour stack's staple) costs a SIMD of this device right now, eight waves per SIMD as the export kernel runs. */
 int rd_measure_valu(int device, double *ns_per_full_rate_instruction);
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);

@@ -2154,8 +2154,10 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
 }
 
 // What one full-rate VALU wave-instruction costs a SIMD on THIS device right now: 512 x 1024 threads (8 waves per SIMD, as
-// the export kernel runs), eight independent v_fma_f32 chains per lane.  bench.py prices the export kernels' static
-// instruction budgets (profiles/isa_budget.json, in units of half a full-rate instruction) with it: valu_issue_frac.
+// the export kernel runs), eight independent chains per lane of alternating v_mul_f32 / v_add_f32 -- the two-operand forms
+// the strict colour stack is made of (tools/valu_probe2.hip: 1.05 ns per instruction for this pair, 1.20 ns for the
+// three-operand v_fma_f32; the cheaper one is the honest price for a LOWER bound on issue time).  bench.py prices the
+// export kernels' static instruction budgets (profiles/isa_budget.json, in units of half such an instruction) with it.
 __global__ void __launch_bounds__(1024) rd_probe_valu(float *out, float a, float b, int iters)
 {
     float av = a, bv = b, x[8];
@@ -2166,7 +2168,10 @@ __global__ void __launch_bounds__(1024) rd_probe_valu(float *out, float a, float
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(av), "v"(bv));
+            for (int i = 0; i < 8; ++i) {
+                if (r & 1) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(bv));
+                else asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(av));
+            }
     }
     float s = 0.0f;
 #pragma unroll

@@ -2,7 +2,7 @@
 # Round-4 evidence pass on one GPU box.   bash tools/gpu_r4_evidence.sh [tag] [part]
 #   part a: smoke, the -m gpu suite, the driver's bench command, the other hosts, rocprofv3 kernel stats of the same command,
 #           the threshold table against the oracle for all 2^32 encodings
-#   part b: differential fuzz + soak of the final build, rocprofv3 PMC passes (tools/gpu_pmc.sh)
+#   part b: differential fuzz + soak of the final build;  part c: rocprofv3 PMC passes (tools/gpu_pmc.sh)
 set -u
 TAG=${1:-r04}; PART=${2:-a}
 OUT=gpurun_out/$TAG
@@ -32,9 +32,10 @@ if [ "$PART" = a ]; then
     for f in $(find "$OUT/rocprof" -name "*kernel_stats*.csv" | head -1); do head -14 "$f" | cut -c1-200; done
     step 600 "$OUT/q8_exhaustive_lut.txt" ./tools/q8_exhaustive --lut
     cat "$OUT/q8_exhaustive_lut.txt"
-else
+elif [ "$PART" = b ]; then
     step 900 "$OUT/fuzz.log" python -m tests.fuzz_parity 100000 44
     step 600 "$OUT/soak.log" python tools/soak.py 10000
+else
     bash tools/gpu_pmc.sh "$TAG"
 fi
 echo "== done"
