@@ -402,7 +402,7 @@ def valu_fields(fmt_name, W, H, us_per_frame, valu_ns, n_simd=1024):
             "valu_source": f"profiles/isa_budget.json [{b['kernel']}] (static count from hipcc's assembly, bench workload's path) priced with "
                            "rd_measure_valu of this run (a v_mul / v_add loop at full occupancy, right after the timed region); a static "
                            "issue bound: stalls, LDS and memory waits come on top, and the part may clock a memory-bound kernel higher "
-                           "than the calibration loop, so for the f32 surface the fraction is an upper estimate"}
+                           "than the calibration loop: read the fraction as +-5 % (it can exceed 1 by a few per cent), for the f32 surface as an upper estimate"}
 
 
 def bound_of(fmt_name, hbm_frac, valu):

@@ -2213,7 +2213,7 @@ extern "C" int rd_measure_valu(int device, double *ns_per_full_rate_instruction)
     if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_measure_valu: %s", hipGetErrorString(e));
     std::sort(ms.begin(), ms.end());
     const double per_simd = (double)blocks * 16.0 * 8.0 * 4.0 * iters / ((double)n_cu * 4.0);     // wave-instructions each SIMD issued
-    *ns_per_full_rate_instruction = ms[ms.size() / 2] * 1e6 / per_simd;
+    *ns_per_full_rate_instruction = ms.front() * 1e6 / per_simd;      // the fastest of five: the clock the part reaches under pure VALU load
     return RD_OK;
 }
 
