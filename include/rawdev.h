@@ -349,6 +349,8 @@ int rd_stream_destroy(int device, void *stream);
  * the stream must re-zero them and come out right. */
 int rd_debug_poison_scheduler(rd_pipeline *p, void *stream);
 uint32_t rd_debug_scheduler_entries(rd_pipeline *p);   /* streams this pipeline currently keeps state for (<= 16) */
+uint32_t rd_debug_lane_count(rd_pipeline *p);          /* render lanes this pipeline has created so far (<= 4) */
+int rd_debug_is_pinned_host(const void *ptr, size_t len);   /* 1: a render into [ptr, ptr + len) takes the direct-DMA path */
 /* devices[index]'s own 768 x u64 histogram buffer as the last rd_node_batch_histogram left it (after an all-reduce every
  * device holds the global sum). */
 int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768]);

@@ -116,6 +116,8 @@ PROTOTYPES = {
     "rd_stream_destroy": (_I, [_I, _VP]),
     "rd_debug_poison_scheduler": (_I, [_VP, _VP]),
     "rd_debug_scheduler_entries": (_U32, [_VP]),
+    "rd_debug_lane_count": (_U32, [_VP]),
+    "rd_debug_is_pinned_host": (_I, [_VP, _SZ]),
     "rd_debug_node_histogram_of": (_I, [_VP, _U32, _VP]),
 }
 

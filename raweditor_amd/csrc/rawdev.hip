@@ -2296,6 +2296,16 @@ extern "C" int rd_debug_poison_scheduler(rd_pipeline *p, void *stream)
 
 extern "C" uint32_t rd_debug_scheduler_entries(rd_pipeline *p) { return p ? (uint32_t)p->scratch.size() : 0u; }
 
+// render lanes this pipeline has created so far (<= RD_LANES_MAX), and whether a host range would take the direct-DMA path
+extern "C" uint32_t rd_debug_lane_count(rd_pipeline *p)
+{
+    if (!p) return 0u;
+    std::lock_guard<std::mutex> lk(p->lane_mu);
+    return (uint32_t)p->lanes.size();
+}
+
+extern "C" int rd_debug_is_pinned_host(const void *ptr, size_t len) { return ptr && rd_is_pinned_host(ptr, len) ? 1 : 0; }
+
 extern "C" int rd_device_synchronize(int device)
 {
     rd_devguard g(device);

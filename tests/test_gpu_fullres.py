@@ -154,3 +154,83 @@ def test_export_races_uniform_updates_without_tearing(gpu_lib, refc):
         t.join()
     assert sum(seen) == 24
     pipe.close()
+
+
+def test_page_locked_destinations_are_detected(gpu_lib):
+    """The direct-DMA path is taken for page-locked memory however it was obtained (rd_host_alloc, a HIP host allocation made
+    by somebody else -- torch's pin_memory here) and for every sub-range of it; ordinary memory is staged."""
+    import ctypes as C
+    import torch
+    ra = gpu_lib
+    from raweditor_amd import _lib
+    L = _lib.lib()
+    n = 24 << 20
+    pin = ra.PinnedBytes(n)
+    assert L.rd_debug_is_pinned_host(C.c_void_p(pin.ptr), n) == 1
+    assert L.rd_debug_is_pinned_host(C.c_void_p(pin.ptr + 4096), n - 8192) == 1
+    t = torch.empty(n, dtype=torch.uint8).pin_memory()
+    assert L.rd_debug_is_pinned_host(C.c_void_p(t.data_ptr()), n) == 1
+    plain = np.empty(n, np.uint8)
+    assert L.rd_debug_is_pinned_host(plain.ctypes.data_as(C.c_void_p), n) == 0
+    assert L.rd_debug_is_pinned_host(None, n) == 0
+    # a render into torch's pinned tensor (the same bytes as any other destination)
+    h, w = 2056, 2048
+    rng = np.random.default_rng([0x52415745, 91])
+    cfa = random_cfa(rng, h, w)
+    pipe = ra.RenderPipeline.new(4, cfa.reshape(-1), w, h, ra.EditParams(), WB_DAYLIGHT, CM_TEST)
+    out_t = torch.empty(h * w * 4, dtype=torch.uint8).pin_memory()
+    a = pipe.render_full_res_to_bytes(out=out_t.numpy())
+    b = pipe.render_full_res_to_bytes()
+    assert np.array_equal(a, b)
+    pin.free()
+    pipe.close()
+
+
+def test_six_threads_share_four_render_lanes(gpu_lib, refc):
+    """More concurrent host renders than lanes: every call takes a lane for its duration, the fifth and sixth wait for one;
+    previews, histogram renders, calculate_histogram, f32 renders with a fused histogram and band-pipelined exports all
+    come out bit-identical to the oracle, and the pipeline never holds more than four lanes."""
+    ra = gpu_lib
+    from raweditor_amd import _lib
+    h, w = 2056, 2048
+    rng = np.random.default_rng([0x52415745, 92])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = ra.RenderPipeline.new(6, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+    u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST)
+    f32 = refc.render_f32(cfa, u, nthreads=8)
+    full8 = refc.pack_u8(f32)
+    hist_full = refc.histogram(full8)
+    prev8 = _oracle8(refc, cfa, params, tw=pipe.preview_width, th=pipe.preview_height)
+    hb8 = _oracle8(refc, cfa, params, tw=pipe.histogram_width, th=pipe.histogram_height)
+    hist_small = refc.histogram(hb8)
+    bad = []
+
+    def work(k):
+        try:
+            for it in range(8):
+                kind = (k + it) % 5
+                if kind == 0:
+                    ok = np.array_equal(pipe.render_to_bytes().reshape(prev8.shape), prev8)
+                elif kind == 1:
+                    hb = pipe.render_to_histogram_bytes()
+                    ok = np.array_equal(hb.reshape(hb8.shape), hb8) and np.array_equal(pipe.calculate_histogram(hb), hist_small)
+                elif kind == 2:
+                    ok = np.array_equal(pipe.render_full_res_to_bytes().reshape(h, w, 4), full8)
+                elif kind == 3:
+                    got, hist = pipe.render(fmt=ra.FMT_RGBA_F32, with_histogram=True)
+                    ok = np.array_equal(got.view(np.uint32), f32.view(np.uint32)) and np.array_equal(hist, hist_full)
+                else:
+                    got, hist = pipe.render(fmt=ra.FMT_RGBA_U8, with_histogram=True)
+                    ok = np.array_equal(got, full8) and np.array_equal(hist, hist_full)
+                if not ok:
+                    bad.append((k, it, kind))
+        except Exception as e:  # noqa: BLE001
+            bad.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad, bad
+    assert 2 <= _lib.lib().rd_debug_lane_count(pipe._h) <= 4
+    pipe.close()
