@@ -662,6 +662,23 @@ def extra_full_res_to_bytes(torch, np, ra, dev, dev_index, cfa_t, p, iters=24):
             notes.append(str(info))
         res[name] = {"ms": round(med, 3), "ms_min": round(mn, 3), "GBps_over_pcie": round(nbytes / med / 1e6, 1),
                      "MP_per_s": round(W * H / med / 1e3, 1), "limiter": limiter}
+    # the allocation-free form: the pipeline lends a page-locked surface (rd_render_full_res_borrow)
+    ms = []
+    for it in range(iters + 4):
+        t0 = time.perf_counter()
+        with pipe.render_full_res_borrowed() as sfc:
+            ms.append((time.perf_counter() - t0) * 1e3)
+            if it == iters + 3:
+                ok, info = check_bands("u8", W, H, cfa_t, p, torch.from_numpy(np.array(sfc.array, copy=True)), "strict", "borrowed")
+                ok_all = ok_all and ok
+                if not ok:
+                    notes.append(str(info))
+    ms = ms[4:]
+    med = statistics.median(ms)
+    res["borrowed_surface"] = {"ms": round(med, 3), "ms_min": round(min(ms), 3), "GBps_over_pcie": round(nbytes / med / 1e6, 1),
+                               "MP_per_s": round(W * H / med / 1e3, 1),
+                               "limiter": "PCIe; rd_render_full_res_borrow: the pipeline lends its own page-locked surface (no allocation, "
+                                          "no page faults, no host copy on the caller's side)"}
     # the floor: the same bytes, device -> page-locked host, one hipMemcpyAsync on a stream, nothing else
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()

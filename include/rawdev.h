@@ -34,7 +34,7 @@ extern "C" {
  * 3: no signature changed.  Host renders no longer serialise on the pipeline (each call takes a render lane; the mutex only
  * guards the uniforms) and a full-resolution render is band-pipelined (see rd_render_full_res_to_bytes); new entry points
  * rd_host_alloc / rd_host_free (page-locked render destinations), rd_measure_hbm (the box's own streaming ceilings),
- * rd_measure_valu, rd_device_identity, rd_selftest_q8_lut (+ _codes), rd_q8_lut_table. */
+ * rd_render_full_res_borrow / rd_surface_release (a lent page-locked surface), rd_measure_valu, rd_device_identity, rd_selftest_q8_lut (+ _codes), rd_q8_lut_table. */
 #define RD_ABI_VERSION 3
 
 typedef enum rd_status {
@@ -163,6 +163,13 @@ int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
  * UI thread proceeds on another render lane (the uniforms are snapshotted when the call starts -- like the reference, the
  * export uses whatever view() wrote last, main.rs:1515 vs :1754). */
 int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
+/* The same render without an allocation on the caller's side: the width x height RGBA8 surface is rendered into page-locked
+ * memory the pipeline owns (allocated on first use, reused afterwards) and LENT to the caller: *data stays valid until
+ * rd_surface_release(p, *data).  This is what export_image_async needs -- a byte slice for image::save_buffer
+ * (main.rs:1765-1791) -- at the price of the PCIe transfer, with no page faults and no host copy.  Up to four surfaces may be
+ * out at a time; they are freed with the pipeline (release them first). */
+int rd_render_full_res_borrow(rd_pipeline *p, const uint8_t **data, size_t *len);
+int rd_surface_release(rd_pipeline *p, const uint8_t *data);
 /* render_to_histogram_bytes (pipeline.rs:615-716): histogram_width x histogram_height RGBA8. */
 int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len);
 /* calculate_histogram (pipeline.rs:720-736): [R[256], G[256], B[256]] counts of RGBA8 bytes

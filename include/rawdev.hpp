@@ -193,6 +193,29 @@ public:
         check(rd_render_full_res_to_bytes(h_, v.data(), v.size()));
         return v;
     }
+    // The export without an allocation: a page-locked surface the pipeline owns, lent until the Surface goes out of scope.
+    class Surface {
+    public:
+        Surface(rd_pipeline *p, const uint8_t *d, size_t n) : p_(p), d_(d), n_(n) {}
+        Surface(Surface &&o) noexcept : p_(o.p_), d_(o.d_), n_(o.n_) { o.d_ = nullptr; }
+        Surface(const Surface &) = delete;
+        Surface &operator=(const Surface &) = delete;
+        ~Surface() { if (d_) rd_surface_release(p_, d_); }
+        const uint8_t *data() const { return d_; }
+        size_t size() const { return n_; }
+
+    private:
+        rd_pipeline *p_;
+        const uint8_t *d_;
+        size_t n_;
+    };
+    Surface render_full_res() const
+    {
+        const uint8_t *d = nullptr;
+        size_t n = 0;
+        check(rd_render_full_res_borrow(h_, &d, &n));
+        return Surface(h_, d, n);
+    }
     // The same render into memory the caller keeps: a reused buffer (no first-touch page faults) or PinnedBytes (direct DMA).
     void render_full_res_into(uint8_t *dst, size_t len) const { check(rd_render_full_res_to_bytes(h_, dst, len)); }
     std::vector<uint8_t> render_to_histogram_bytes() const                                              // :615

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "rd_render_to_bytes": (_I, [_VP, _VP, _SZ]),
     "rd_render_full_res_to_bytes": (_I, [_VP, _VP, _SZ]),
     "rd_render_to_histogram_bytes": (_I, [_VP, _VP, _SZ]),
+    "rd_render_full_res_borrow": (_I, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rd_surface_release": (_I, [_VP, _VP]),
     "rd_calculate_histogram": (_I, [_VP, _VP, _SZ, _VP]),
     "rd_render": (_I, [_VP, _U32, _U32, _U32, _VP, _SZ, _VP]),
     "rd_render_device": (_I, [_VP, _U32, _U32, _U32, _VP, _VP, _VP]),

@@ -586,6 +586,10 @@ struct rd_pipeline {
     };
     std::mutex graph_mu;
     std::map<hipStream_t, graph_cache> graphs;
+    // page-locked surfaces lent to the caller (rd_render_full_res_borrow): allocated once, reused, freed with the pipeline
+    struct lent { void *ptr = nullptr; size_t cap = 0; bool busy = false; };
+    std::mutex lent_mu;
+    std::vector<lent> lents;
 };
 
 static void rd_lane_free(rd_lane *l)             // device set, nothing of the lane in flight
@@ -746,6 +750,8 @@ extern "C" void rd_pipeline_destroy(rd_pipeline *p)
         p->lanes.clear();
         for (auto &kv : p->graphs) { if (kv.second.ex) (void)hipGraphExecDestroy(kv.second.ex); if (kv.second.g) (void)hipGraphDestroy(kv.second.g); }
         p->graphs.clear();
+        for (auto &b : p->lents) if (b.ptr) (void)hipHostFree(b.ptr);
+        p->lents.clear();
         if (p->owns_cfa && p->cfa) (void)hipFree((void *)p->cfa);
         (void)hipDeviceSynchronize();        // renders enqueued on caller streams (rd_render_device) may still draw tickets
         p->scratch.release();
@@ -895,18 +901,26 @@ extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, 
 }
 
 // Is [ptr, ptr + n) page-locked host memory the DMA engines can write (hipHostMalloc / rd_host_alloc / hipHostRegister)?
-static bool rd_is_pinned_host(const void *ptr, size_t n)
+enum { RD_MEM_PAGEABLE = 0, RD_MEM_PINNED = 1, RD_MEM_DEVICE = 2 };
+static int rd_host_memory_kind(const void *ptr, size_t n)
 {
-    if (getenv("RD_ASSUME_PAGEABLE")) return false;          // A/B switch: stage every destination
     const char *ends[2] = { (const char *)ptr, (const char *)ptr + (n ? n - 1 : 0) };
+    int kind = RD_MEM_PINNED;
     for (const char *q : ends) {
         hipPointerAttribute_t a;
         memset(&a, 0, sizeof a);
         const hipError_t e = hipPointerGetAttributes(&a, q);
-        if (e != hipSuccess) { (void)hipGetLastError(); return false; }      // plain malloc memory: "invalid value"
-        if (a.type != hipMemoryTypeHost) return false;
+        if (e != hipSuccess) { (void)hipGetLastError(); kind = RD_MEM_PAGEABLE; continue; }    // plain malloc memory: "invalid value"
+        if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return RD_MEM_DEVICE;
+        if (a.type != hipMemoryTypeHost) kind = RD_MEM_PAGEABLE;       // unregistered / managed: staged
     }
-    return true;
+    return kind;
+}
+
+static bool rd_is_pinned_host(const void *ptr, size_t n)
+{
+    if (getenv("RD_ASSUME_PAGEABLE")) return false;          // A/B switch: stage every destination
+    return rd_host_memory_kind(ptr, n) == RD_MEM_PINNED;
 }
 
 // A pageable destination that has never been touched (the fresh Vec<u8> the reference's signature returns) costs one page
@@ -1003,9 +1017,10 @@ static int rd_render_full_host(rd_pipeline *p, rd_lane *l, const rd_shot &sh, ui
             e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->compute);
             if (e == hipSuccess) e = hipStreamSynchronize(l->compute);
         }
-        if (e != hipSuccess) { (void)hipStreamSynchronize(l->copy); (void)hipStreamSynchronize(l->compute); }
     }
     if (e != hipSuccess) {                                    // whatever ran may have stopped half way: counters are suspect
+        (void)hipStreamSynchronize(l->copy);                  // nothing may still be writing `dst` when the caller gets it back
+        (void)hipStreamSynchronize(l->compute);
         p->scratch.mark_all_dirty();
         return rd_fail(RD_ERR_HIP, "render readback failed: %s", hipGetErrorString(e));
     }
@@ -1023,6 +1038,8 @@ extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_
     if (dst_len != need) return rd_fail(RD_ERR_INVALID_ARG, "dst_len %zu != %ux%ux%zu = %zu", dst_len, out_w, out_h, bpp, need);
     rd_devguard g(p->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+    if (need >= RD_BAND_MIN_BYTES && rd_host_memory_kind(dst, need) == RD_MEM_DEVICE)      // (the staged path would memcpy into it)
+        return rd_fail(RD_ERR_INVALID_ARG, "dst is device memory: rd_render writes host buffers (rd_render_device takes device pointers)");
     const rd_shot sh = rd_pipeline_snapshot(p);               // the pipeline's mutex is held for this line only
     rd_lane_hold hold(p, need);
     rd_lane *l = hold.l;
@@ -1053,6 +1070,57 @@ extern "C" int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t 
 {
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     return rd_render(p, p->info.width, p->info.height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
+}
+
+// render_full_res_to_bytes without the caller's allocation: the surface is rendered into page-locked memory the PIPELINE owns
+// (allocated on first use, reused afterwards: pinning 96.6 MB costs milliseconds, a fresh pageable Vec its page faults) and
+// lent to the caller until rd_surface_release.  What export_image_async needs -- a &[u8] for image::save_buffer
+// (main.rs:1765-1791) -- at the price of the PCIe transfer.  Up to RD_LENT_MAX surfaces may be out at a time.
+#define RD_LENT_MAX 4
+extern "C" int rd_render_full_res_borrow(rd_pipeline *p, const uint8_t **data, size_t *len)
+{
+    if (!p || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    *data = nullptr;
+    const size_t need = (size_t)p->info.width * p->info.height * 4u;
+    rd_devguard g(p->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+    void *buf = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->lent_mu);
+        for (auto &b : p->lents)
+            if (!b.busy && b.cap >= need) { b.busy = true; buf = b.ptr; break; }
+        if (!buf) {
+            if (p->lents.size() >= RD_LENT_MAX) return rd_fail(RD_ERR_INVALID_ARG, "%d borrowed surfaces have not been released", RD_LENT_MAX);
+            rd_pipeline::lent b;
+            RD_HIP(hipHostMalloc(&b.ptr, need, hipHostMallocDefault));
+            b.cap = need; b.busy = true;
+            p->lents.push_back(b);
+            buf = b.ptr;
+        }
+    }
+    const int rc = rd_render(p, p->info.width, p->info.height, RD_FMT_RGBA_U8, buf, need, nullptr);
+    if (rc) {
+        std::lock_guard<std::mutex> lk(p->lent_mu);
+        for (auto &b : p->lents) if (b.ptr == buf) b.busy = false;
+        return rc;
+    }
+    *data = (const uint8_t *)buf;
+    if (len) *len = need;
+    return RD_OK;
+}
+
+extern "C" int rd_surface_release(rd_pipeline *p, const uint8_t *data)
+{
+    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
+    if (!data) return RD_OK;
+    std::lock_guard<std::mutex> lk(p->lent_mu);
+    for (auto &b : p->lents)
+        if (b.ptr == (const void *)data) {
+            if (!b.busy) return rd_fail(RD_ERR_INVALID_ARG, "surface released twice");
+            b.busy = false;
+            return RD_OK;
+        }
+    return rd_fail(RD_ERR_INVALID_ARG, "not a surface borrowed from this pipeline");
 }
 
 extern "C" int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)

@@ -79,6 +79,27 @@ class PinnedBytes:
             pass
 
 
+class BorrowedSurface:
+    """A surface lent by rd_render_full_res_borrow; give it back with release() (or use it as a context manager)."""
+
+    def __init__(self, pipe, ptr: int, nbytes: int):
+        self._pipe, self.ptr, self.nbytes = pipe, ptr, nbytes
+        self.array = np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=np.uint8)
+
+    def release(self) -> None:
+        if self.ptr:
+            self.array = None
+            check(_lib.lib().rd_surface_release(self._pipe._h, C.c_void_p(self.ptr)))
+            self.ptr = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+        return False
+
+
 def measure_hbm(device: int = 0, nbytes: int = 1 << 30, reps: int = 5):
     """(copy, fill, read, hipMemsetAsync) GB/s of this device right now (rd_measure_hbm: librawdev's own streaming kernels)."""
     v = [C.c_double() for _ in range(4)]
@@ -181,6 +202,13 @@ class RenderPipeline:
         """`out` (optional): the destination to fill instead of a fresh array -- a PinnedBytes(...).array takes the
         direct-DMA path, any other array the staged one (rd_render_full_res_to_bytes in include/rawdev.h)."""
         return self._bytes(_lib.lib().rd_render_full_res_to_bytes, self.width, self.height, out)
+
+    def render_full_res_borrowed(self):
+        """render_full_res_to_bytes into page-locked memory the pipeline owns: returns a BorrowedSurface whose `.array` is the
+        uint8 view (valid until `.release()` / the end of the `with` block).  No allocation, no page faults, no host copy."""
+        data, n = C.c_void_p(), C.c_size_t()
+        check(_lib.lib().rd_render_full_res_borrow(self._h, C.byref(data), C.byref(n)))
+        return BorrowedSurface(self, data.value, n.value)
 
     def render_to_histogram_bytes(self) -> np.ndarray:                            # pipeline.rs:615-716
         return self._bytes(_lib.lib().rd_render_to_histogram_bytes, self.histogram_width, self.histogram_height)

@@ -136,6 +136,10 @@ static void test_pipeline_gpu()
     bool threw = false;
     try { pipe.render_full_res_into(mine.data(), mine.size() - 4); } catch (const rawdev::Error &) { threw = true; }
     EXPECT(threw);
+    {
+        const rawdev::RenderPipeline::Surface lent = pipe.render_full_res();       // the pipeline's own page-locked surface
+        EXPECT(lent.size() == exp8.size() && std::memcmp(lent.data(), exp8.data(), exp8.size()) == 0);
+    }
 }
 
 // The node-level batch entry through the C++ mirror: 5 frames on one device, surfaces and u64 histogram against the oracle.

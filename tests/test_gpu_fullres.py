@@ -173,6 +173,9 @@ def test_page_locked_destinations_are_detected(gpu_lib):
     plain = np.empty(n, np.uint8)
     assert L.rd_debug_is_pinned_host(plain.ctypes.data_as(C.c_void_p), n) == 0
     assert L.rd_debug_is_pinned_host(None, n) == 0
+    from tests.gpu_util import DevBuf
+    dbuf = DevBuf(n)
+    assert L.rd_debug_is_pinned_host(C.c_void_p(dbuf.ptr), n) == 0          # device memory is not a host destination ...
     # a render into torch's pinned tensor (the same bytes as any other destination)
     h, w = 2056, 2048
     rng = np.random.default_rng([0x52415745, 91])
@@ -182,6 +185,9 @@ def test_page_locked_destinations_are_detected(gpu_lib):
     a = pipe.render_full_res_to_bytes(out=out_t.numpy())
     b = pipe.render_full_res_to_bytes()
     assert np.array_equal(a, b)
+    # ... and a full-resolution host render refuses it instead of memcpy-ing into it
+    assert L.rd_render_full_res_to_bytes(pipe._h, C.c_void_p(dbuf.ptr), h * w * 4) == -1
+    assert b"device memory" in L.rd_last_error()
     pin.free()
     pipe.close()
 
@@ -233,4 +239,37 @@ def test_six_threads_share_four_render_lanes(gpu_lib, refc):
     [t.join() for t in ts]
     assert not bad, bad
     assert 2 <= _lib.lib().rd_debug_lane_count(pipe._h) <= 4
+    pipe.close()
+
+
+def test_borrowed_surface(gpu_lib, refc):
+    """rd_render_full_res_borrow: the export into page-locked memory the pipeline owns and lends; the same bytes, the same
+    buffer again after a release, at most four out at a time, a foreign or double release is an error."""
+    import ctypes as C
+    ra = gpu_lib
+    from raweditor_amd import _lib
+    h, w = 2056, 2048
+    rng = np.random.default_rng([0x52415745, 93])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = ra.RenderPipeline.new(8, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+    exp = _oracle8(refc, cfa, params)
+    with pipe.render_full_res_borrowed() as s:
+        first = s.ptr
+        assert s.nbytes == h * w * 4 and _lib.lib().rd_debug_is_pinned_host(C.c_void_p(s.ptr), s.nbytes) == 1
+        assert np.array_equal(s.array.reshape(h, w, 4), exp)
+    with pipe.render_full_res_borrowed() as s:
+        assert s.ptr == first                                  # reused, not re-allocated
+        assert np.array_equal(s.array.reshape(h, w, 4), exp)
+    out = [pipe.render_full_res_borrowed() for _ in range(4)]
+    assert len({s.ptr for s in out}) == 4
+    with pytest.raises(ra.RawdevError):
+        pipe.render_full_res_borrowed()                        # a fifth while four are out
+    assert all(np.array_equal(s.array.reshape(h, w, 4), exp) for s in out)
+    p0 = out[0].ptr
+    out[0].release()
+    assert _lib.lib().rd_surface_release(pipe._h, C.c_void_p(p0)) == -1          # released twice
+    assert _lib.lib().rd_surface_release(pipe._h, C.c_void_p(p0 + 64)) == -1     # not a surface of this pipeline
+    for s in out[1:]:
+        s.release()
     pipe.close()
