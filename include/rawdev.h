@@ -343,6 +343,7 @@ int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, d
 int rd_measure_valu(int device, double *ns_per_full_rate_instruction);
 int rd_device_malloc(int device, size_t bytes, void **out);
 int rd_device_free(int device, void *ptr);
+int rd_device_memory(int device, size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo */
 int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes);
 int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t bytes);
 int rd_device_synchronize(int device);

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "rd_measure_valu": (_I, [_I, C.POINTER(C.c_double)]),
     "rd_device_malloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_device_free": (_I, [_I, _VP]),
+    "rd_device_memory": (_I, [_I, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "rd_memcpy_h2d": (_I, [_I, _VP, _VP, _SZ]),
     "rd_memcpy_d2h": (_I, [_I, _VP, _VP, _SZ]),
     "rd_device_synchronize": (_I, [_I]),

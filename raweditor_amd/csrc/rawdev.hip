@@ -2297,6 +2297,17 @@ extern "C" int rd_device_malloc(int device, size_t bytes, void **out)
     return RD_OK;
 }
 
+extern "C" int rd_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
+{
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    size_t f = 0, t = 0;
+    RD_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return RD_OK;
+}
+
 extern "C" int rd_device_free(int device, void *ptr)
 {
     if (!ptr) return RD_OK;

@@ -273,3 +273,44 @@ def test_borrowed_surface(gpu_lib, refc):
     for s in out[1:]:
         s.release()
     pipe.close()
+
+
+def test_pipeline_per_image_does_not_leak(gpu_lib, refc):
+    """The reference builds a new RenderPipeline for every image it opens (main.rs:993-1006, drop at :1028): forty pipelines,
+    each used the way the app uses one (preview, histogram render, a staged export, a lent surface, a direct-DMA export),
+    then dropped -- device memory ends where it started (lanes, staging slots, lent surfaces, scheduler state, the graph
+    cache and the CFA copy all go with the pipeline)."""
+    import ctypes as C
+    ra = gpu_lib
+    from raweditor_amd import _lib
+
+    def free_mb():
+        f, t = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib().rd_device_memory(0, C.byref(f), C.byref(t)))
+        return f.value / 2**20
+
+    h, w = 2056, 2048
+    rng = np.random.default_rng([0x52415745, 94])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    exp = _oracle8(refc, cfa, params)
+    pin = ra.PinnedBytes(h * w * 4)
+
+    def one(i):
+        pipe = ra.RenderPipeline.new(i, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+        pipe.render_to_bytes()
+        pipe.calculate_histogram(pipe.render_to_histogram_bytes())
+        a = pipe.render_full_res_to_bytes()
+        with pipe.render_full_res_borrowed() as s:
+            ok = np.array_equal(s.array, a)
+        pipe.render_full_res_to_bytes(out=pin.array)
+        ok = ok and np.array_equal(pin.array, a) and (i % 10 or np.array_equal(a.reshape(h, w, 4), exp))
+        pipe.close()
+        return ok
+
+    assert one(0)                                              # first use: library-level one-time allocations
+    before = free_mb()
+    assert all(one(i) for i in range(1, 41))
+    after = free_mb()
+    assert before - after < 64, f"device memory shrank by {before - after:.0f} MiB over 40 pipelines"
+    pin.free()
