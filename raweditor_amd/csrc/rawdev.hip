@@ -8,7 +8,10 @@
 //   * uniforms are kernel arguments (no uniform buffer, no write_buffer);
 //   * linear buffers, not textures: no 8192-px texture limit (pipeline.rs:164), so 100 MP frames
 //     need no special casing.
-// There is no CPU compute path in this file: every render is a gfx950 kernel launch.
+// There is no CPU compute path in this library: every render is a gfx950 kernel launch.
+// Layout (one translation unit): this file = errors, device bookkeeping, launch plumbing, ingest helper, plumbing, test hooks;
+// rd_host_pipeline.inl = rd_pipeline; rd_host_batch.inl = rd_batch / rd_node_batch / rd_exporter; rd_host_diag.inl = self-tests
+// and measurement aids.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -448,1649 +451,9 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
     return RD_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// host-side copy pool: staging buffer -> caller's pageable destination on several cores
-// ------------------------------------------------------------------------------------------------
-// A render into PAGEABLE host memory (a Rust Vec<u8>, a numpy array) cannot be the target of a DMA: the surface goes
-// device -> pinned staging -> destination, and the second hop is a CPU memcpy.  One core moves ~10 GB/s (less while it
-// takes the first-touch page faults of a fresh destination), PCIe delivers ~56 GB/s, so the hop is spread over a few
-// helper threads.  Process-wide, started on first use, never joined (the object is leaked on purpose: no destructor
-// runs against waiting threads at exit).  RD_COPY_THREADS = helpers (default 4; 0 = the calling thread alone).
-namespace {
-struct rd_copy_pool {
-    struct job { char *d; const char *s; size_t n; };
-    std::mutex run_mu;                         // one parallel copy at a time
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::vector<job> jobs;
-    size_t next = 0, pending = 0;
-    unsigned helpers = 0;
-
-    static rd_copy_pool &get()
-    {
-        static rd_copy_pool *pool = [] {
-            rd_copy_pool *p = new rd_copy_pool;
-            const char *e = getenv("RD_COPY_THREADS");
-            long want = e && *e ? strtol(e, nullptr, 10) : 4;
-            const long hw = (long)std::thread::hardware_concurrency();
-            if (hw > 0 && want > hw - 1) want = hw - 1;
-            if (want < 0) want = 0;
-            if (want > 16) want = 16;
-            for (long i = 0; i < want; ++i) {
-                try { std::thread([p] { p->work(); }).detach(); p->helpers += 1; } catch (...) { break; }
-            }
-            return p;
-        }();
-        return *pool;
-    }
-    bool take(job &j)                           // caller holds mu
-    {
-        if (next >= jobs.size()) return false;
-        j = jobs[next++];
-        return true;
-    }
-    void work()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            job j;
-            if (!take(j)) { cv_work.wait(lk); continue; }
-            lk.unlock();
-            memcpy(j.d, j.s, j.n);
-            lk.lock();
-            if (--pending == 0) cv_done.notify_all();
-        }
-    }
-    // dst[0..n) = src[0..n), split into 2 MiB-aligned pieces over the helpers and the calling thread
-    void copy(void *dst, const void *src, size_t n)
-    {
-        const size_t parts = helpers + 1u;
-        if (parts == 1u || n < (4u << 20)) { memcpy(dst, src, n); return; }
-        std::lock_guard<std::mutex> run(run_mu);
-        std::unique_lock<std::mutex> lk(mu);
-        jobs.clear(); next = 0;
-        size_t piece = ((n + parts - 1) / parts + ((2u << 20) - 1)) & ~(size_t)((2u << 20) - 1);
-        for (size_t off = 0; off < n; off += piece)
-            jobs.push_back(job{ (char *)dst + off, (const char *)src + off, n - off < piece ? n - off : piece });
-        pending = jobs.size();
-        cv_work.notify_all();
-        for (;;) {                              // the calling thread copies too
-            job j;
-            if (!take(j)) break;
-            lk.unlock();
-            memcpy(j.d, j.s, j.n);
-            lk.lock();
-            --pending;
-        }
-        cv_done.wait(lk, [this] { return pending == 0; });
-    }
-};
-}  // namespace
-
-// ------------------------------------------------------------------------------------------------
-// rd_pipeline
-// ------------------------------------------------------------------------------------------------
-// A render LANE: everything one host-side render call needs besides the CFA plane -- a compute stream, a copy stream,
-// a device surface, a 768-bin histogram, pinned staging for pageable destinations, events.  The reference shares
-// Arc<RenderPipeline> between the UI thread (render_to_bytes + render_to_histogram_bytes per redraw, main.rs:1515-1531)
-// and the export thread (render_full_res_to_bytes, main.rs:1749-1754); each call takes a free lane for its duration, so
-// the 96.6 MB read-back of an export does not stand between a slider move and its preview.  The pipeline's mutex only
-// guards the uniforms: a render snapshots them (rd_shot) and lets go.
-#define RD_LANES_MAX 4
-#define RD_BANDS_MAX 8                           // row-band launches of a full-resolution host render
-#define RD_STAGE_SLOTS 3                         // pinned staging slots of RD_STAGE_BYTES each (pageable destinations)
-#define RD_STAGE_BYTES ((size_t)8 << 20)
-#define RD_BAND_MIN_BYTES ((size_t)16 << 20)     // smaller surfaces: one launch, one copy
-
-struct rd_lane {
-    hipStream_t compute = nullptr, copy = nullptr;
-    void *out_buf = nullptr; size_t out_cap = 0;
-    uint32_t *hist_dev = nullptr;
-    void *stage[RD_STAGE_SLOTS] = {};
-    hipEvent_t kev[RD_BANDS_MAX] = {};           // band k's kernel has finished (compute stream)
-    hipEvent_t cev[RD_STAGE_SLOTS] = {};         // the copy into staging slot j has finished (copy stream)
-    hipEvent_t done = nullptr;                   // the copy stream has drained this call's chunks
-    bool busy = false;
-};
-
-struct rd_shot {                                 // what a render needs from the pipeline's mutable state
-    rd_ku u;
-    bool export_view;                            // zoom 1, pan 0: the export map may apply
-    uint32_t math_mode;
-};
-
-struct rd_pipeline {
-    int device = 0;
-    rd_info info{};
-    rd_launch_cfg cfg;
-    const uint16_t *cfa = nullptr;
-    bool owns_cfa = false;
-    bool identity_ok = false;
-    rd_edit_params params{};
-    float wb[4]{}, cm[9]{};
-    float zoom = 1.0f, pan_x = 0.0f, pan_y = 0.0f;
-    uint32_t black_level = 0;
-    uint32_t math_mode = RD_MATH_STRICT;
-    uint32_t matrix_layout = RD_MATRIX_REFERENCE;
-    hipStream_t stream = nullptr;     // lane 0's compute stream ("the pipeline's own stream" of the test hooks)
-    rd_scratch scratch;               // per stream: ticket counters + histogram slab (has its own lock)
-    std::mutex mu;                    // the uniforms (Send + Sync like Arc<RenderPipeline>)
-    std::mutex lane_mu;               // the lane pool
-    std::condition_variable lane_cv;
-    std::vector<rd_lane *> lanes;
-    // RD_GRAPH=1 (experiment, profiles/r04_single_frame_gap.txt): develop + histogram fold of a whole-frame render as ONE
-    // two-node graph per stream, re-parameterised (hipGraphExecKernelNodeSetParams) and launched per call
-    struct graph_cache {
-        hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr; hipGraphNode_t n_dev = nullptr, n_fold = nullptr;
-        const void *fn = nullptr; uint32_t blocks = 0;
-    };
-    std::mutex graph_mu;
-    std::map<hipStream_t, graph_cache> graphs;
-    // page-locked surfaces lent to the caller (rd_render_full_res_borrow): allocated once, reused, freed with the pipeline
-    struct lent { void *ptr = nullptr; size_t cap = 0; bool busy = false; };
-    std::mutex lent_mu;
-    std::vector<lent> lents;
-};
-
-static void rd_lane_free(rd_lane *l)             // device set, nothing of the lane in flight
-{
-    if (!l) return;
-    if (l->compute) { (void)hipStreamSynchronize(l->compute); (void)hipStreamDestroy(l->compute); }
-    if (l->copy) { (void)hipStreamSynchronize(l->copy); (void)hipStreamDestroy(l->copy); }
-    if (l->out_buf) (void)hipFree(l->out_buf);
-    if (l->hist_dev) (void)hipFree(l->hist_dev);
-    for (void *s : l->stage) if (s) (void)hipHostFree(s);
-    for (hipEvent_t e : l->kev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : l->cev) if (e) (void)hipEventDestroy(e);
-    if (l->done) (void)hipEventDestroy(l->done);
-    delete l;
-}
-
-static int rd_lane_new(rd_lane **out)            // device set
-{
-    *out = nullptr;
-    rd_lane *l = new (std::nothrow) rd_lane;
-    if (!l) return rd_fail(RD_ERR_OOM, "host allocation failed");
-    hipError_t e = hipStreamCreateWithFlags(&l->compute, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&l->copy, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&l->hist_dev, 768 * sizeof(uint32_t));
-    for (int k = 0; k < RD_BANDS_MAX && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&l->kev[k], hipEventDisableTiming);
-    for (int k = 0; k < RD_STAGE_SLOTS && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&l->cev[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->done, hipEventDisableTiming);
-    if (e != hipSuccess) {
-        rd_lane_free(l);
-        return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "render lane setup failed: %s", hipGetErrorString(e));
-    }
-    *out = l;
-    return RD_OK;
-}
-
-// A free lane for a render that needs `need` bytes of device surface: the smallest free one that is large enough, else
-// any free one (it grows), else a new one (up to RD_LANES_MAX), else wait for a call to finish.
-static int rd_lane_acquire(rd_pipeline *p, size_t need, rd_lane **out)
-{
-    *out = nullptr;
-    std::unique_lock<std::mutex> lk(p->lane_mu);
-    for (;;) {
-        rd_lane *fit = nullptr, *any = nullptr;
-        for (rd_lane *l : p->lanes) {
-            if (l->busy) continue;
-            if (!any || l->out_cap > any->out_cap) any = l;
-            if (l->out_cap >= need && (!fit || l->out_cap < fit->out_cap)) fit = l;
-        }
-        rd_lane *l = fit;
-        if (!l && any && (p->lanes.size() >= RD_LANES_MAX || need <= RD_BAND_MIN_BYTES || any->out_cap == 0)) l = any;
-        if (!l && p->lanes.size() < RD_LANES_MAX) {
-            const int rc = rd_lane_new(&l);
-            if (rc) return rc;
-            p->lanes.push_back(l);
-        }
-        if (!l && any) l = any;
-        if (l) { l->busy = true; *out = l; return RD_OK; }
-        p->lane_cv.wait(lk);
-    }
-}
-
-static void rd_lane_release(rd_pipeline *p, rd_lane *l)
-{
-    { std::lock_guard<std::mutex> lk(p->lane_mu); l->busy = false; }
-    p->lane_cv.notify_one();
-}
-
-struct rd_lane_hold {                            // RAII: a lane for the duration of one call
-    rd_pipeline *p; rd_lane *l = nullptr; int rc;
-    rd_lane_hold(rd_pipeline *pp, size_t need) : p(pp) { rc = rd_lane_acquire(pp, need, &l); }
-    ~rd_lane_hold() { if (l) rd_lane_release(p, l); }
-};
-
-static int rd_lane_reserve(rd_lane *l, size_t need)          // the lane's device surface holds `need` bytes
-{
-    if (l->out_cap >= need) return RD_OK;
-    if (l->out_buf) { (void)hipFree(l->out_buf); l->out_buf = nullptr; l->out_cap = 0; }
-    RD_HIP(hipMalloc(&l->out_buf, need));
-    l->out_cap = need;
-    return RD_OK;
-}
-
-static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bool cfa_on_device,
-                           uint32_t w, uint32_t h, const rd_edit_params *params, const float wb[4],
-                           const float cm[9], rd_pipeline **out)
-{
-    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    if (!cfa || !params || !wb || !cm) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
-    if ((uint64_t)w * h >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u exceeds 2^32 pixels", w, h);
-    int n_cu = 0;
-    int rc = rd_check_device(device, &n_cu);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-
-    rc = rd_q8_lut_ensure(device);
-    if (rc) return rc;
-    rd_pipeline *p = new (std::nothrow) rd_pipeline;
-    if (!p) return rd_fail(RD_ERR_OOM, "host allocation failed");
-    p->device = device;
-    p->cfg.n_cu = n_cu;
-    p->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
-    p->info.width = w; p->info.height = h; p->info.image_id = image_id;
-    rd_derived_dims(w, h, &p->info.preview_width, &p->info.preview_height, &p->info.histogram_width,
-                    &p->info.histogram_height);
-    p->params = *params;
-    memcpy(p->wb, wb, sizeof p->wb);
-    memcpy(p->cm, cm, sizeof p->cm);
-    p->identity_ok = rd_identity_map(w) && rd_identity_map(h);
-
-    rd_lane *l0 = nullptr;
-    rc = rd_lane_new(&l0);
-    if (rc) { rd_pipeline_destroy(p); return rc; }
-    p->lanes.push_back(l0);
-    p->stream = l0->compute;
-    hipError_t e = hipSuccess;
-    if (cfa_on_device) {
-        p->cfa = cfa;
-    } else {
-        void *d = nullptr;
-        e = hipMalloc(&d, (size_t)w * h * sizeof(uint16_t));
-        if (e == hipSuccess) {
-            p->cfa = (const uint16_t *)d; p->owns_cfa = true;
-            e = hipMemcpy(d, cfa, (size_t)w * h * sizeof(uint16_t), hipMemcpyHostToDevice);
-        }
-    }
-    if (e != hipSuccess) {
-        int code = rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "pipeline setup failed: %s", hipGetErrorString(e));
-        rd_pipeline_destroy(p);
-        return code;
-    }
-    *out = p;
-    return RD_OK;
-}
-
-extern "C" int rd_pipeline_create(int device, int64_t image_id, const uint16_t *cfa, uint32_t w, uint32_t h,
-                                  const rd_edit_params *params, const float wb[4], const float cm[9],
-                                  rd_pipeline **out)
-{
-    return rd_pipeline_new(device, image_id, cfa, false, w, h, params, wb, cm, out);
-}
-
-extern "C" int rd_pipeline_create_from_device(int device, int64_t image_id, const uint16_t *cfa_dev, uint32_t w,
-                                              uint32_t h, const rd_edit_params *params, const float wb[4],
-                                              const float cm[9], rd_pipeline **out)
-{
-    return rd_pipeline_new(device, image_id, cfa_dev, true, w, h, params, wb, cm, out);
-}
-
-extern "C" void rd_pipeline_destroy(rd_pipeline *p)
-{
-    if (!p) return;
-    {
-        rd_devguard g(p->device);
-        for (rd_lane *l : p->lanes) rd_lane_free(l);
-        p->lanes.clear();
-        for (auto &kv : p->graphs) { if (kv.second.ex) (void)hipGraphExecDestroy(kv.second.ex); if (kv.second.g) (void)hipGraphDestroy(kv.second.g); }
-        p->graphs.clear();
-        for (auto &b : p->lents) if (b.ptr) (void)hipHostFree(b.ptr);
-        p->lents.clear();
-        if (p->owns_cfa && p->cfa) (void)hipFree((void *)p->cfa);
-        (void)hipDeviceSynchronize();        // renders enqueued on caller streams (rd_render_device) may still draw tickets
-        p->scratch.release();
-    }
-    delete p;
-}
-
-extern "C" int rd_pipeline_info(const rd_pipeline *p, rd_info *out)
-{
-    if (!p || !out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    *out = p->info;
-    return RD_OK;
-}
-
-extern "C" int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t bl)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    std::lock_guard<std::mutex> lk(p->mu);
-    p->black_level = bl;
-    return RD_OK;
-}
-
-extern "C" int rd_pipeline_set_matrix_layout(rd_pipeline *p, uint32_t layout)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    if (layout != RD_MATRIX_REFERENCE && layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", layout);
-    std::lock_guard<std::mutex> lk(p->mu);
-    p->matrix_layout = layout;
-    return RD_OK;
-}
-
-extern "C" int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t mode)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
-    std::lock_guard<std::mutex> lk(p->mu);
-    p->math_mode = mode;
-    return RD_OK;
-}
-
-extern "C" int rd_update_uniforms_with_zoom(rd_pipeline *p, const rd_edit_params *params, float zoom, float pan_x,
-                                            float pan_y)
-{
-    if (!p || !params) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(p->mu);
-    p->params = *params;     // wb / matrix are preserved, as in pipeline.rs:375-381
-    p->zoom = zoom; p->pan_x = pan_x; p->pan_y = pan_y;
-    return RD_OK;
-}
-
-extern "C" int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params)
-{
-    return rd_update_uniforms_with_zoom(p, params, 1.0f, 0.0f, 0.0f);   // pipeline.rs:367-369
-}
-
-// The uniforms as they stand now: the only thing a render reads under the pipeline's mutex.  (The reference's export
-// re-uses whatever view() last wrote, main.rs:1515 vs :1754; a snapshot keeps that and removes the tear a concurrent
-// queue.write_buffer can cause there.)
-static rd_shot rd_pipeline_snapshot(rd_pipeline *p)
-{
-    std::lock_guard<std::mutex> lk(p->mu);
-    rd_shot s;
-    s.u = rd_frame_ku(p->params, p->wb, p->cm, p->zoom, p->pan_x, p->pan_y, p->black_level, p->math_mode, p->matrix_layout);
-    s.export_view = p->zoom == 1.0f && p->pan_x == 0.0f && p->pan_y == 0.0f;
-    s.math_mode = p->math_mode;
-    return s;
-}
-
-// Does a tw x th render of this snapshot take the export kernel (one 2x2 block per lane, identity map)?
-static bool rd_pipeline_uses_quads(const rd_pipeline *p, const rd_shot &sh, uint32_t tw, uint32_t th, uint32_t fmt)
-{
-    const uint32_t W = p->info.width, H = p->info.height;
-    return tw == W && th == H && sh.export_view && (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
-           (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
-}
-
-// Enqueue one render of the snapshot on stream s: units [unit0, unit1) of the export kernel (the whole frame is
-// [0, H/2 + 1)), or the map kernel for any other target.  The device is set.  With hist_dev the launch must be the whole frame.
-static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, uint32_t th, uint32_t fmt, void *dst_dev,
-                               uint32_t *hist_dev, hipStream_t s, uint32_t unit0 = 0, uint32_t unit1 = 0)
-{
-    if (!tw || !th) return rd_fail(RD_ERR_INVALID_ARG, "empty target %ux%u", tw, th);
-    if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    if ((uintptr_t)dst_dev % rd_align_for(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "dst is not %zu-byte aligned", rd_align_for(fmt));
-    const uint32_t W = p->info.width, H = p->info.height;
-    const bool quads = rd_pipeline_uses_quads(p, sh, tw, th, fmt);
-    if (!unit1) unit1 = H / 2u + 1u;
-    uint32_t blocks = 0;
-    const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
-    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    static const bool use_graph = rd_env_u32("RD_GRAPH", 0) != 0;
-    if (use_graph && quads && hist_dev && unit0 == 0u && unit1 == H / 2u + 1u) {
-        rd_quads_call call;
-        int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, sh.u, true, unit0, unit1, true, sh.math_mode,
-                                   l.slab32, nullptr, 0, l.tq, s, &blocks, &call);
-        if (rc == RD_OK) {
-            uint32_t *slab = l.slab32, nb = blocks, *hd = hist_dev;
-            void *fold_args[3] = { &slab, &nb, &hd };
-            hipKernelNodeParams kd{}, kf{};
-            kd.func = const_cast<void *>(call.fn); kd.gridDim = dim3(call.blocks); kd.blockDim = dim3(RD_BLOCK); kd.kernelParams = call.argv;
-            kf.func = (void *)rd_reduce_slab32; kf.gridDim = dim3(24); kf.blockDim = dim3(RD_FOLD_THREADS); kf.kernelParams = fold_args;
-            std::lock_guard<std::mutex> gl(p->graph_mu);
-            if (p->graphs.size() > 16 && !p->graphs.count(s)) {              // bounded like the scheduler state
-                for (auto &kv : p->graphs) { if (kv.second.ex) (void)hipGraphExecDestroy(kv.second.ex); if (kv.second.g) (void)hipGraphDestroy(kv.second.g); }
-                p->graphs.clear();
-            }
-            rd_pipeline::graph_cache &gc = p->graphs[s];
-            hipError_t e = hipSuccess;
-            if (!gc.ex || gc.fn != call.fn || gc.blocks != call.blocks) {
-                if (gc.ex) (void)hipGraphExecDestroy(gc.ex);
-                if (gc.g) (void)hipGraphDestroy(gc.g);
-                gc = rd_pipeline::graph_cache{};
-                e = hipGraphCreate(&gc.g, 0);
-                if (e == hipSuccess) e = hipGraphAddKernelNode(&gc.n_dev, gc.g, nullptr, 0, &kd);
-                if (e == hipSuccess) e = hipGraphAddKernelNode(&gc.n_fold, gc.g, &gc.n_dev, 1, &kf);
-                if (e == hipSuccess) e = hipGraphInstantiate(&gc.ex, gc.g, nullptr, nullptr, 0);
-                gc.fn = call.fn; gc.blocks = call.blocks;
-            } else {
-                e = hipGraphExecKernelNodeSetParams(gc.ex, gc.n_dev, &kd);
-                if (e == hipSuccess) e = hipGraphExecKernelNodeSetParams(gc.ex, gc.n_fold, &kf);
-            }
-            if (e == hipSuccess) e = hipGraphLaunch(gc.ex, s);
-            if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "graph launch failed: %s", hipGetErrorString(e));
-        }
-        p->scratch.used(l, s, rc != RD_OK);
-        return rc;
-    }
-    int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, sh.u, quads, unit0, unit1,
-                               hist_dev != nullptr, sh.math_mode, l.slab32, nullptr, 0, l.tq, s, &blocks);
-    if (rc == RD_OK && hist_dev) {
-        hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, s, l.slab32, blocks, hist_dev);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "histogram fold launch failed: %s", hipGetErrorString(e));
-    }
-    p->scratch.used(l, s, rc != RD_OK);
-    return rc;
-}
-
-extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst_dev,
-                                uint32_t *hist_dev, void *stream)
-{
-    if (!p || !dst_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    rd_devguard g(p->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    const rd_shot sh = rd_pipeline_snapshot(p);
-    return rd_pipeline_enqueue(p, sh, out_w, out_h, fmt, dst_dev, hist_dev, (hipStream_t)stream);
-}
-
-// Is [ptr, ptr + n) page-locked host memory the DMA engines can write (hipHostMalloc / rd_host_alloc / hipHostRegister)?
-enum { RD_MEM_PAGEABLE = 0, RD_MEM_PINNED = 1, RD_MEM_DEVICE = 2 };
-static int rd_host_memory_kind(const void *ptr, size_t n)
-{
-    const char *ends[2] = { (const char *)ptr, (const char *)ptr + (n ? n - 1 : 0) };
-    int kind = RD_MEM_PINNED;
-    for (const char *q : ends) {
-        hipPointerAttribute_t a;
-        memset(&a, 0, sizeof a);
-        const hipError_t e = hipPointerGetAttributes(&a, q);
-        if (e != hipSuccess) { (void)hipGetLastError(); kind = RD_MEM_PAGEABLE; continue; }    // plain malloc memory: "invalid value"
-        if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return RD_MEM_DEVICE;
-        if (a.type != hipMemoryTypeHost) kind = RD_MEM_PAGEABLE;       // unregistered / managed: staged
-    }
-    return kind;
-}
-
-static bool rd_is_pinned_host(const void *ptr, size_t n)
-{
-    if (getenv("RD_ASSUME_PAGEABLE")) return false;          // A/B switch: stage every destination
-    return rd_host_memory_kind(ptr, n) == RD_MEM_PINNED;
-}
-
-// A pageable destination that has never been touched (the fresh Vec<u8> the reference's signature returns) costs one page
-// fault per 4 KiB inside the staging memcpy: 23 600 faults for a 24 MP RGBA8 surface, several times the PCIe transfer.
-// Two hints were tried on the GPU box (THP mode "madvise", kernel 6.18; profiles/r04_fullres_ab.txt) and neither pays:
-// MADV_HUGEPAGE on the 2 MiB-aligned interior (46 faults instead of 23 600, but each compacts and zeroes 2 MiB: 8.0 ms
-// against 6.5 ms without it) and MADV_POPULATE_WRITE (7.9 ms).  So the default is to do nothing -- the faults are the
-// caller's, a reused or page-locked destination avoids them -- and RD_DST_ADVISE=huge | populate keeps the experiment.
-static void rd_advise_destination(char *dst, size_t n)
-{
-    static const int mode = [] { const char *e = getenv("RD_DST_ADVISE"); return !e || !*e ? 0 : !strcmp(e, "huge") ? 1 : !strcmp(e, "populate") ? 2 : 0; }();
-    if (!mode || n < ((size_t)8 << 20)) return;
-    const uintptr_t huge = (uintptr_t)2 << 20;
-    const uintptr_t lo = ((uintptr_t)dst + huge - 1) & ~(huge - 1), hi = ((uintptr_t)dst + n) & ~(huge - 1);
-    if (hi <= lo) return;
-#ifdef MADV_HUGEPAGE
-    if (mode == 1) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
-#endif
-#ifdef MADV_POPULATE_WRITE
-    if (mode == 2) (void)madvise((void *)lo, hi - lo, MADV_POPULATE_WRITE);
-#endif
-}
-
-// Full-resolution host render (render_full_res_to_bytes, pipeline.rs:526-606, and rd_render of the whole frame): the
-// reference renders, copies the texture into a MAP_READ buffer, blocks in poll(Wait) and de-pads 96.6 MB row by row
-// ("1-2 seconds for 24MP", pipeline.rs:525).  Here, on the lane's two streams:
-//   * the frame is launched as up to RD_BANDS_MAX row bands (the export kernel takes a unit range; a band's rows are
-//     contiguous bytes of the surface), so the first bytes cross PCIe while the later bands are still being computed;
-//   * a page-locked destination (rd_host_alloc / hipHostMalloc / hipHostRegister; detected) is written by the DMA
-//     engine directly, in chunks, all enqueued at once: one synchronise, no host copy;
-//   * a pageable destination goes through RD_STAGE_SLOTS pinned slots of 8 MiB: the DMA of chunk c+3 runs while the
-//     copy pool moves chunk c into the caller's buffer.
-// With a fused histogram the slab is written by ONE launch (no bands); the copies are chunked all the same.
-static int rd_render_full_host(rd_pipeline *p, rd_lane *l, const rd_shot &sh, uint32_t fmt, char *dst, size_t need, uint32_t *hist)
-{
-    const uint32_t W = p->info.width, H = p->info.height;
-    const size_t row_bytes = (size_t)W * rd_format_bytes_per_pixel(fmt);
-    const uint32_t units = H / 2u + 1u;
-    static const uint32_t bands_env = rd_env_u32("RD_RENDER_BANDS", RD_BANDS_MAX);
-    uint32_t bands = hist ? 1u : (bands_env < RD_BANDS_MAX ? bands_env : RD_BANDS_MAX);
-    if (bands > units) bands = units;
-    if (!bands) bands = 1u;
-    size_t band_end[RD_BANDS_MAX];                           // bytes of the surface complete after band k
-    int rc = RD_OK;
-    for (uint32_t k = 0; k < bands && rc == RD_OK; ++k) {
-        const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands), u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
-        const uint32_t row_hi = 2u * (u1 - 1u) < H ? 2u * (u1 - 1u) + 1u : H;      // exclusive: the last unit's row b
-        band_end[k] = k + 1u == bands ? need : (size_t)row_hi * row_bytes;
-        rc = rd_pipeline_enqueue(p, sh, W, H, fmt, l->out_buf, hist ? l->hist_dev : nullptr, l->compute, u0, u1);
-        if (rc == RD_OK) RD_HIP(hipEventRecord(l->kev[k], l->compute));
-    }
-    if (rc) return rc;
-    const bool pinned = rd_is_pinned_host(dst, need);
-    static const size_t chunk_pinned = (size_t)rd_env_u32("RD_COPY_CHUNK_MB", 16) << 20;
-    const size_t chunk = pinned ? chunk_pinned : RD_STAGE_BYTES;
-    const size_t nchunks = (need + chunk - 1) / chunk;
-    uint32_t waited = 0;                                     // bands [0, waited) are already ordered before the copy stream's tail
-    auto enqueue_chunk = [&](size_t c, void *to) -> hipError_t {
-        const size_t off = c * chunk, len = need - off < chunk ? need - off : chunk;
-        hipError_t e = hipSuccess;
-        while (e == hipSuccess && waited < bands && (waited == 0 || band_end[waited - 1u] < off + len))
-            e = hipStreamWaitEvent(l->copy, l->kev[waited++], 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(to, (const char *)l->out_buf + off, len, hipMemcpyDeviceToHost, l->copy);
-        return e;
-    };
-    hipError_t e = hipSuccess;
-    if (pinned) {
-        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) e = enqueue_chunk(c, dst + c * chunk);
-        if (e == hipSuccess && hist) {
-            e = hipStreamWaitEvent(l->copy, l->kev[0], 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->copy);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(l->copy);
-    } else {
-        for (int j = 0; j < RD_STAGE_SLOTS && e == hipSuccess; ++j)
-            if (!l->stage[j]) e = hipHostMalloc(&l->stage[j], RD_STAGE_BYTES, hipHostMallocDefault);
-        for (size_t c = 0; c < nchunks && c < RD_STAGE_SLOTS && e == hipSuccess; ++c) {
-            e = enqueue_chunk(c, l->stage[c]);
-            if (e == hipSuccess) e = hipEventRecord(l->cev[c], l->copy);
-        }
-        rd_copy_pool &pool = rd_copy_pool::get();
-        rd_advise_destination(dst, need);
-        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
-            const size_t j = c % RD_STAGE_SLOTS, off = c * chunk, len = need - off < chunk ? need - off : chunk;
-            e = hipEventSynchronize(l->cev[j]);
-            if (e != hipSuccess) break;
-            pool.copy(dst + off, l->stage[j], len);
-            if (c + RD_STAGE_SLOTS < nchunks) {              // the slot is free again: the chunk three ahead goes into it
-                e = enqueue_chunk(c + RD_STAGE_SLOTS, l->stage[j]);
-                if (e == hipSuccess) e = hipEventRecord(l->cev[j], l->copy);
-            }
-        }
-        if (e == hipSuccess && hist) {
-            e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->compute);
-            if (e == hipSuccess) e = hipStreamSynchronize(l->compute);
-        }
-    }
-    if (e != hipSuccess) {                                    // whatever ran may have stopped half way: counters are suspect
-        (void)hipStreamSynchronize(l->copy);                  // nothing may still be writing `dst` when the caller gets it back
-        (void)hipStreamSynchronize(l->compute);
-        p->scratch.mark_all_dirty();
-        return rd_fail(RD_ERR_HIP, "render readback failed: %s", hipGetErrorString(e));
-    }
-    return RD_OK;
-}
-
-extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst, size_t dst_len,
-                         uint32_t hist[768])
-{
-    if (!p || !dst) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    const size_t bpp = rd_format_bytes_per_pixel(fmt);
-    if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    const size_t need = (size_t)out_w * out_h * bpp;
-    if (!need) return rd_fail(RD_ERR_INVALID_ARG, "empty target %ux%u", out_w, out_h);
-    if (dst_len != need) return rd_fail(RD_ERR_INVALID_ARG, "dst_len %zu != %ux%ux%zu = %zu", dst_len, out_w, out_h, bpp, need);
-    rd_devguard g(p->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    if (need >= RD_BAND_MIN_BYTES && rd_host_memory_kind(dst, need) == RD_MEM_DEVICE)      // (the staged path would memcpy into it)
-        return rd_fail(RD_ERR_INVALID_ARG, "dst is device memory: rd_render writes host buffers (rd_render_device takes device pointers)");
-    const rd_shot sh = rd_pipeline_snapshot(p);               // the pipeline's mutex is held for this line only
-    rd_lane_hold hold(p, need);
-    rd_lane *l = hold.l;
-    if (!l) return hold.rc;
-    int rc = rd_lane_reserve(l, need);
-    if (rc) return rc;
-    if (need >= RD_BAND_MIN_BYTES && rd_pipeline_uses_quads(p, sh, out_w, out_h, fmt))
-        return rd_render_full_host(p, l, sh, fmt, (char *)dst, need, hist);
-    rc = rd_pipeline_enqueue(p, sh, out_w, out_h, fmt, l->out_buf, hist ? l->hist_dev : nullptr, l->compute);
-    if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dst, l->out_buf, need, hipMemcpyDeviceToHost, l->compute);
-    if (e == hipSuccess && hist) e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->compute);
-    if (e == hipSuccess) e = hipStreamSynchronize(l->compute);
-    if (e != hipSuccess) {                                    // whatever ran may have stopped half way: counters are suspect
-        p->scratch.mark_all_dirty();
-        return rd_fail(RD_ERR_HIP, "render readback failed: %s", hipGetErrorString(e));
-    }
-    return RD_OK;
-}
-
-extern "C" int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    return rd_render(p, p->info.preview_width, p->info.preview_height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
-}
-
-extern "C" int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    return rd_render(p, p->info.width, p->info.height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
-}
-
-// render_full_res_to_bytes without the caller's allocation: the surface is rendered into page-locked memory the PIPELINE owns
-// (allocated on first use, reused afterwards: pinning 96.6 MB costs milliseconds, a fresh pageable Vec its page faults) and
-// lent to the caller until rd_surface_release.  What export_image_async needs -- a &[u8] for image::save_buffer
-// (main.rs:1765-1791) -- at the price of the PCIe transfer.  Up to RD_LENT_MAX surfaces may be out at a time.
-#define RD_LENT_MAX 4
-extern "C" int rd_render_full_res_borrow(rd_pipeline *p, const uint8_t **data, size_t *len)
-{
-    if (!p || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    *data = nullptr;
-    const size_t need = (size_t)p->info.width * p->info.height * 4u;
-    rd_devguard g(p->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    void *buf = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(p->lent_mu);
-        for (auto &b : p->lents)
-            if (!b.busy && b.cap >= need) { b.busy = true; buf = b.ptr; break; }
-        if (!buf) {
-            if (p->lents.size() >= RD_LENT_MAX) return rd_fail(RD_ERR_INVALID_ARG, "%d borrowed surfaces have not been released", RD_LENT_MAX);
-            rd_pipeline::lent b;
-            RD_HIP(hipHostMalloc(&b.ptr, need, hipHostMallocDefault));
-            b.cap = need; b.busy = true;
-            p->lents.push_back(b);
-            buf = b.ptr;
-        }
-    }
-    const int rc = rd_render(p, p->info.width, p->info.height, RD_FMT_RGBA_U8, buf, need, nullptr);
-    if (rc) {
-        std::lock_guard<std::mutex> lk(p->lent_mu);
-        for (auto &b : p->lents) if (b.ptr == buf) b.busy = false;
-        return rc;
-    }
-    *data = (const uint8_t *)buf;
-    if (len) *len = need;
-    return RD_OK;
-}
-
-extern "C" int rd_surface_release(rd_pipeline *p, const uint8_t *data)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    if (!data) return RD_OK;
-    std::lock_guard<std::mutex> lk(p->lent_mu);
-    for (auto &b : p->lents)
-        if (b.ptr == (const void *)data) {
-            if (!b.busy) return rd_fail(RD_ERR_INVALID_ARG, "surface released twice");
-            b.busy = false;
-            return RD_OK;
-        }
-    return rd_fail(RD_ERR_INVALID_ARG, "not a surface borrowed from this pipeline");
-}
-
-extern "C" int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
-{
-    if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
-    return rd_render(p, p->info.histogram_width, p->info.histogram_height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
-}
-
-extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_t rgba_len, uint32_t hist[768])
-{
-    if (!p || !hist || (!rgba && rgba_len)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (rgba_len % 4) return rd_fail(RD_ERR_INVALID_ARG, "rgba_len %zu is not a multiple of 4", rgba_len);
-    const size_t npx = rgba_len / 4;
-    if (npx >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "too many pixels");
-    if (!npx) { memset(hist, 0, 768 * sizeof(uint32_t)); return RD_OK; }
-    rd_devguard g(p->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
-    rd_lane_hold hold(p, rgba_len);
-    rd_lane *ln = hold.l;
-    if (!ln) return hold.rc;
-    int rc = rd_lane_reserve(ln, rgba_len);
-    if (rc) return rc;
-    RD_HIP(hipMemcpyAsync(ln->out_buf, rgba, rgba_len, hipMemcpyHostToDevice, ln->compute));
-    const uint32_t blocks = rd_blocks_for(p->cfg, npx, true);
-    const rd_scratch::lease l = p->scratch.get(ln->compute, true);
-    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    hipLaunchKernelGGL(rd_hist_u8, dim3(blocks), dim3(RD_BLOCK), 0, ln->compute, (const uint32_t *)ln->out_buf,
-                       (uint32_t)npx, l.slab32);
-    hipLaunchKernelGGL(rd_reduce_slab32, dim3(24), dim3(RD_FOLD_THREADS), 0, ln->compute, l.slab32, blocks, ln->hist_dev);
-    const hipError_t le = hipGetLastError();
-    p->scratch.used(l, ln->compute, le != hipSuccess);
-    RD_HIP(le);
-    RD_HIP(hipMemcpyAsync(hist, ln->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, ln->compute));
-    RD_HIP(hipStreamSynchronize(ln->compute));
-    return RD_OK;
-}
-
-// Page-locked host memory for render destinations (and sources): what a host that wants the direct-DMA path allocates
-// its surface buffer from.  Any thread, any time; rd_host_free(NULL) is a no-op.
-extern "C" int rd_host_alloc(int device, size_t bytes, void **out)
-{
-    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    RD_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
-    return RD_OK;
-}
-
-extern "C" int rd_host_free(int device, void *ptr)
-{
-    if (!ptr) return RD_OK;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    RD_HIP(hipHostFree(ptr));
-    return RD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// rd_batch
-// ------------------------------------------------------------------------------------------------
-struct rd_batch {
-    int device = 0;
-    uint32_t w = 0, h = 0, fmt = 0;
-    bool hist = false;
-    bool identity_ok = false;
-    uint32_t math_mode = RD_MATH_STRICT;
-    rd_launch_cfg cfg;
-    uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
-    // RD_BATCH_STREAMS=2: launches alternate between the caller's stream and an internal one (forked from and joined back
-    // into the caller's stream inside rd_batch_develop), so the next frame's workgroups move in as the previous frame's
-    // finish.  Concurrent launches need their own slab rows and ticket counters.  Measured +2.4 % (strict) / -2 %
-    // (contracted) on 256 x 24 MP: not the default.
-    uint32_t n_streams = 1;
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    unsigned long long *slab64 = nullptr;      // n_streams x blocks x 768
-    rd_scratch scratch;                        // per stream: ticket counters
-    // Multi-frame launches (the default; RD_BATCH_PERSISTENT=0 falls back to one launch per frame / row band): the
-    // frames of a call reach the kernel as an array of descriptors in HBM.  Two arrays with pinned staging; an array is
-    // rewritten only when the caller's frames differ from what it holds (bench.py re-submits the same batch every
-    // step), and only after the launches that read it have finished (`done`).
-    bool persistent = true;
-    uint32_t max_frames = 8;                   // RD_BATCH_MAX_FRAMES: frames per launch (default 8 for f32, 32 otherwise)
-    struct desc_buf {
-        rd_frame_desc *dev = nullptr, *host = nullptr;
-        size_t cap = 0, n = 0;
-        hipEvent_t done = nullptr;             // after the last launch that reads the array
-        hipEvent_t uploaded = nullptr;         // after the copy that filled it (a later call may come on another stream)
-        bool valid = false;
-    } db[2];
-    int db_last = 1;
-    uint32_t last_launches = 0;                // fused launches enqueued by the last rd_batch_develop call
-};
-
-extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
-                               rd_batch **out)
-{
-    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
-    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
-    if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs width %% 128 == 0 (got %u)", w);
-    const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
-    if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
-    int n_cu = 0;
-    int rc = rd_check_device(device, &n_cu);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    rc = rd_q8_lut_ensure(device);
-    if (rc) return rc;
-    rd_batch *b = new (std::nothrow) rd_batch;
-    if (!b) return rd_fail(RD_ERR_OOM, "host allocation failed");
-    b->device = device; b->w = w; b->h = h; b->fmt = fmt; b->hist = with_histogram != 0;
-    b->cfg.n_cu = n_cu;
-    b->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
-    b->cfg.wg_per_cu_hist = rd_env_u32("RD_WG_PER_CU_HIST", 2);      // experiment builds with a smaller RD_BLOCK only
-    b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
-    if (!b->identity_ok) { delete b; return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h); }
-    b->blocks = rd_blocks_for(b->cfg, items, b->hist);
-    b->n_streams = rd_env_u32("RD_BATCH_STREAMS", 1) >= 2 ? 2u : 1u;
-    {
-        const char *pe = getenv("RD_BATCH_PERSISTENT");
-        b->persistent = !(pe && *pe == '0') && b->n_streams == 1;
-        // f32: 8 is the flat bottom of the curve; the narrow surfaces are arithmetic-bound and only
-        // lose launch tails as launches grow (u8 48.7 / 48.6 / 48.2, f16 61.2 / 60.6 / 60.2 us per frame at 8 / 16 / 32)
-        b->max_frames = rd_env_u32("RD_BATCH_MAX_FRAMES", fmt == RD_FMT_RGBA_F32 ? 8u : 32u);
-    }
-    hipError_t e = hipSuccess;
-    for (int j = 0; j < 2 && e == hipSuccess && b->persistent; ++j) {
-        e = hipEventCreateWithFlags(&b->db[j].done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->db[j].uploaded, hipEventDisableTiming);
-    }
-    if (b->n_streams > 1) {
-        e = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
-    }
-    if (e == hipSuccess && b->hist) {
-        const size_t bytes = (size_t)b->n_streams * b->blocks * 768 * sizeof(unsigned long long);
-        e = hipMalloc((void **)&b->slab64, bytes);
-        if (e == hipSuccess) e = hipMemset(b->slab64, 0, bytes);
-    }
-    if (e != hipSuccess) {
-        const int code = rd_fail(RD_ERR_OOM, "batch resources: %s", hipGetErrorString(e));
-        rd_batch_destroy(b);
-        return code;
-    }
-    *out = b;
-    return RD_OK;
-}
-
-extern "C" void rd_batch_destroy(rd_batch *b)
-{
-    if (!b) return;
-    {
-        rd_devguard g(b->device);
-        (void)hipDeviceSynchronize();        // launches on the caller's streams still use the slab and the tickets
-        if (b->slab64) (void)hipFree(b->slab64);
-        b->scratch.release();
-        for (auto &d : b->db) {
-            if (d.dev) (void)hipFree(d.dev);
-            if (d.host) (void)hipHostFree(d.host);
-            if (d.done) (void)hipEventDestroy(d.done);
-            if (d.uploaded) (void)hipEventDestroy(d.uploaded);
-        }
-        if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-        if (b->aux) (void)hipStreamDestroy(b->aux);
-    }
-    delete b;
-}
-
-extern "C" int rd_batch_set_math_mode(rd_batch *b, uint32_t mode)
-{
-    if (!b) return rd_fail(RD_ERR_INVALID_ARG, "NULL batch");
-    if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
-    b->math_mode = mode;
-    return RD_OK;
-}
-
-// How many frames one multi-frame launch may hold for frames of w x h: the 32-bit tile index, the u32 histogram bins a
-// workgroup keeps in LDS for the whole launch (every pixel of the launch could, in principle, land in one bin of one
-// workgroup), and the per-format default / RD_BATCH_MAX_FRAMES cap.
-static uint64_t rd_frames_per_launch_limit(uint32_t w, uint32_t h, bool hist, uint32_t cap)
-{
-    const uint32_t tpu = ((w >> 1) + 63u) / 64u;
-    const uint64_t tpf = (uint64_t)(h / 2u + 1u) * tpu;
-    uint64_t kmax = 0xfffffffeull / tpf;
-    if (hist) { const uint64_t k2 = 0xffffffffull / ((uint64_t)w * h); if (k2 < kmax) kmax = k2; }
-    if (kmax > 4096) kmax = 4096;
-    if (cap && cap < kmax) kmax = cap;
-    return kmax < 1 ? 1 : kmax;
-}
-
-// Frames of the next launch, starting at frame i0: as many consecutive frames as the limit allows whose surfaces
-// ([out, out + surf_bytes)) overlap none of the launch's earlier ones.
-static size_t rd_next_launch_size(const rd_frame *frames, size_t n, size_t i0, size_t surf_bytes, uint64_t kmax)
-{
-    size_t c = 1;
-    for (; i0 + c < n && c < kmax; ++c) {
-        const uintptr_t o = (uintptr_t)frames[i0 + c].out_dev;
-        bool clash = false;
-        for (size_t k = 0; k < c && !clash; ++k) {
-            const uintptr_t p = (uintptr_t)frames[i0 + k].out_dev;
-            clash = o < p + surf_bytes && p < o + surf_bytes;
-        }
-        if (clash) break;
-    }
-    return c;
-}
-
-// No device needed: the launches rd_batch_develop would cut a call into (frames per launch, in order).  Returns the number
-// of launches, or a negative rd_status; at most `counts_cap` entries are written.
-extern "C" int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t format, uint32_t with_histogram,
-                                      const rd_frame *frames, size_t n_frames, uint32_t max_frames, uint32_t *counts,
-                                      size_t counts_cap)
-{
-    const size_t bpp = rd_format_bytes_per_pixel(format);
-    if (!width || !height || !bpp || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "rd_batch_plan_launches: bad argument");
-    const uint32_t cap = max_frames ? max_frames : (format == RD_FMT_RGBA_F32 ? 8u : 32u);
-    const uint64_t kmax = rd_frames_per_launch_limit(width, height, with_histogram != 0, cap);
-    const size_t surf = (size_t)width * height * bpp;
-    int launches = 0;
-    for (size_t i0 = 0; i0 < n_frames;) {
-        const size_t c = rd_next_launch_size(frames, n_frames, i0, surf, kmax);
-        if (counts && (size_t)launches < counts_cap) counts[launches] = (uint32_t)c;
-        ++launches;
-        i0 += c;
-    }
-    return launches;
-}
-
-// The multi-frame path of rd_batch_develop: descriptors -> HBM (only when they changed), then as few launches as the
-// limits allow.  A launch never holds two frames whose surfaces overlap (the order in which the tiles of DIFFERENT frames
-// are stored inside one launch is not defined), never more pixels than a u32 histogram bin can count, and never more
-// tiles than the 32-bit tile index.  Row bands need no launches of their own here: the ticket front sweeps a frame in
-// row order, so a "band" is a range of tickets.
-static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n, hipStream_t s)
-{
-    if (!n) return RD_OK;
-    const size_t bpp = rd_format_bytes_per_pixel(b->fmt);
-    const size_t surf_bytes = (size_t)b->w * b->h * bpp;
-    static thread_local std::vector<rd_frame_desc> tmp;
-    tmp.resize(n);
-    memset(tmp.data(), 0, n * sizeof(rd_frame_desc));
-    bool aligned16 = true;
-    for (size_t f = 0; f < n; ++f) {
-        const rd_frame &fr = frames[f];
-        if (!fr.cfa_dev || !fr.out_dev) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f);
-        if ((uintptr_t)fr.cfa_dev % 4u) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f);
-        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f);
-        if ((uintptr_t)fr.cfa_dev % 16u) aligned16 = false;
-        tmp[f].cfa = fr.cfa_dev;
-        tmp[f].out = fr.out_dev;
-        if (fr.matrix_layout != RD_MATRIX_REFERENCE && fr.matrix_layout != RD_MATRIX_ROW_MAJOR)
-            return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: unknown matrix layout %u", f, fr.matrix_layout);
-        tmp[f].u = rd_frame_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level, b->math_mode, fr.matrix_layout);
-        static const bool no_elide = rd_env_u32("RD_NO_ELIDE", 0) != 0;
-        if (no_elide) tmp[f].u.elide = 0u;
-    }
-    // descriptor array in HBM: reuse, or rewrite the one not used by the previous call
-    int j = -1;
-    for (int k = 0; k < 2; ++k)
-        if (b->db[k].valid && b->db[k].n == n && memcmp(b->db[k].host, tmp.data(), n * sizeof(rd_frame_desc)) == 0) j = k;
-    if (j < 0) {
-        j = b->db_last ^ 1;
-        rd_batch::desc_buf &d = b->db[j];
-        RD_HIP(hipEventSynchronize(d.done));                 // launches that read this array (two calls ago) have finished
-        d.valid = false;
-        if (d.cap < n) {
-            if (d.dev) { (void)hipFree(d.dev); d.dev = nullptr; }
-            if (d.host) { (void)hipHostFree(d.host); d.host = nullptr; }
-            d.cap = 0;
-            const size_t cap = n < 64 ? 64 : n;
-            RD_HIP(hipMalloc((void **)&d.dev, cap * sizeof(rd_frame_desc)));
-            RD_HIP(hipHostMalloc((void **)&d.host, cap * sizeof(rd_frame_desc), hipHostMallocDefault));
-            d.cap = cap;
-        }
-        memcpy(d.host, tmp.data(), n * sizeof(rd_frame_desc));
-        RD_HIP(hipMemcpyAsync(d.dev, d.host, n * sizeof(rd_frame_desc), hipMemcpyHostToDevice, s));
-        RD_HIP(hipEventRecord(d.uploaded, s));
-        d.n = n;
-        d.valid = true;
-    } else {
-        RD_HIP(hipStreamWaitEvent(s, b->db[j].uploaded, 0));     // reused array: its copy may have been enqueued on another stream
-    }
-    b->db_last = j;
-    const rd_frame_desc *descs = b->db[j].dev;
-
-    const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->hist, b->max_frames);
-    const rd_scratch::lease l = b->scratch.get(s, false);
-    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    uint32_t *tq = l.tq;
-    int rc = RD_OK;
-    b->last_launches = 0;
-    (void)hipGetLastError();                     // see rd_enqueue_render
-    for (size_t i0 = 0; i0 < n && rc == RD_OK;) {
-        const size_t c = rd_next_launch_size(frames, n, i0, surf_bytes, kmax);
-        RD_DISPATCH(rd_launch_batch_t, b->fmt, b->hist, b->math_mode, descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16,
-                    b->slab64, tq, s);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "multi-frame launch failed: %s", hipGetErrorString(e));
-        else b->last_launches += 1;
-        i0 += c;
-    }
-    b->scratch.used(l, s, rc != RD_OK);
-    RD_HIP(hipEventRecord(b->db[j].done, s));
-    return rc;
-}
-
-extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, uint32_t row_bands, void *stream)
-{
-    if (!b || (!frames && n)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    rd_devguard g(b->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
-    if (b->persistent) return rd_batch_develop_multi(b, frames, n, (hipStream_t)stream);
-    const uint32_t units = b->h / 2u + 1u;
-    uint32_t bands = row_bands ? row_bands : 1u;
-    if (bands > units) bands = units;
-    hipStream_t lanes[2] = { (hipStream_t)stream, (hipStream_t)stream };
-    const bool fork = b->n_streams > 1 && (uint64_t)n * bands > 1u;
-    if (fork) {
-        RD_HIP(hipEventRecord(b->ev_fork, lanes[0]));
-        RD_HIP(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
-        lanes[1] = b->aux;
-    }
-    int rc = RD_OK;
-    size_t launch = 0;
-    b->last_launches = 0;
-    rd_scratch::lease ls[2] = { b->scratch.get(lanes[0], false), rd_scratch::lease{} };
-    if (fork) ls[1] = b->scratch.get(lanes[1], false);
-    if (ls[0].idx < 0 || (fork && ls[1].idx < 0)) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    for (size_t f = 0; f < n && rc == RD_OK; ++f) {
-        const rd_frame &fr = frames[f];
-        if (!fr.cfa_dev || !fr.out_dev) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f); break; }
-        if ((uintptr_t)fr.cfa_dev % 4u) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f); break; }
-        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f); break; }
-        if (fr.matrix_layout != RD_MATRIX_REFERENCE && fr.matrix_layout != RD_MATRIX_ROW_MAJOR) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: unknown matrix layout %u", f, fr.matrix_layout); break; }
-        const rd_ku u = rd_frame_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level,
-                                    b->math_mode, fr.matrix_layout);
-        for (uint32_t k = 0; k < bands && rc == RD_OK; ++k, ++launch) {
-            const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
-            const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
-            const size_t lane = fork ? (launch & 1u) : 0u;
-            unsigned long long *slab = b->slab64 ? b->slab64 + lane * (size_t)b->blocks * 768u : nullptr;
-            rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0, u1,
-                                   b->hist, b->math_mode, nullptr, slab, b->blocks, ls[lane].tq, lanes[lane], nullptr);
-            if (rc == RD_OK) b->last_launches += 1;
-        }
-    }
-    b->scratch.used(ls[0], lanes[0], rc != RD_OK);
-    if (fork) b->scratch.used(ls[1], lanes[1], rc != RD_OK);
-    if (fork) {                                  // join even after an error: what was enqueued stays ordered
-        RD_HIP(hipEventRecord(b->ev_join, b->aux));
-        RD_HIP(hipStreamWaitEvent(lanes[0], b->ev_join, 0));
-    }
-    return rc;
-}
-
-extern "C" uint32_t rd_batch_last_launch_count(const rd_batch *b) { return b ? b->last_launches : 0u; }
-
-extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
-{
-    if (!b || !hist_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
-    rd_devguard g(b->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
-    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(RD_FOLD_THREADS), 0, (hipStream_t)stream, b->slab64,
-                       b->blocks * b->n_streams, (unsigned long long *)hist_dev);
-    RD_HIP(hipGetLastError());
-    return RD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// rd_node_batch: the batch path over the GPUs of one node from ONE process (SURVEY.md section 8b "Batch", 8e)
-//
-// Frames share nothing (the demosaic clamps at the frame edge, shaders.rs:163-166), so frame i simply belongs to device
-// i mod N; its CFA plane and surface live in that device's HBM and no pixel crosses xGMI.  One rd_batch, one stream and
-// one 768 x u64 histogram per device; enqueueing is done by one host thread per device.  The only exchange is the global
-// histogram: ncclAllReduce(768, ncclUint64, ncclSum) over RCCL (librccl.so is loaded on first use and only when N > 1;
-// u64 because 2048 x 24 MP overflows u32).  With N = 1 there is no communicator.
-// ------------------------------------------------------------------------------------------------
-namespace {
-struct rd_rccl_api {
-    void *handle = nullptr;
-    int (*CommInitAll)(void **, int, const int *) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    std::string error;
-    bool ok = false;
-    bool standin = false;                        // RD_NODE_REDUCE=standin: the tests' stand-in, not RCCL (ranks may share a device)
-};
-constexpr int RD_NCCL_UINT64 = 5, RD_NCCL_SUM = 0;           // rccl.h: ncclUint64, ncclSum
-
-rd_rccl_api &rd_rccl()
-{
-    static rd_rccl_api api;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char *env = getenv("RAWDEV_RCCL_LIB");
-        const char *mode = getenv("RD_NODE_REDUCE");
-        const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        // One RCCL per process: a copy that is already mapped (a PyTorch process has its own) serves us too and wins over
-        // RAWDEV_RCCL_LIB, which only names the file to load when none is.  The exception is explicit:
-        // RD_NODE_REDUCE=standin (tests) loads exactly the file RAWDEV_RCCL_LIB names -- the host-memory stand-in of
-        // tests/cpp/rccl_standin.cpp -- and only then may ranks share a device.
-        if (mode && !strcmp(mode, "standin")) {
-            if (!env || !*env) { api.error = "RD_NODE_REDUCE=standin needs RAWDEV_RCCL_LIB=<the stand-in library>"; return; }
-            api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-            if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
-            api.standin = true;
-        }
-        for (const char *n : { "librccl.so.1", "librccl.so" })
-            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        if (!api.handle && env && *env) {
-            api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-            if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
-        }
-        for (const char *n : names)
-            if (!api.handle && n && *n) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (!api.handle) { api.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return; }
-        auto sym = [&](const char *n) { void *p = dlsym(api.handle, n); if (!p && api.error.empty()) api.error = std::string("librccl.so lacks ") + n; return p; };
-        api.CommInitAll = (int (*)(void **, int, const int *))sym("ncclCommInitAll");
-        api.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
-        api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
-        api.GroupStart = (int (*)())sym("ncclGroupStart");
-        api.GroupEnd = (int (*)())sym("ncclGroupEnd");
-        api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
-        api.ok = api.error.empty();
-    });
-    return api;
-}
-}  // namespace
-
-enum { RD_NODE_REDUCE_NONE = 0, RD_NODE_REDUCE_RCCL = 1, RD_NODE_REDUCE_HOST = 2 };
-
-struct rd_node_batch {
-    uint32_t n = 0, w = 0, h = 0, fmt = 0;
-    bool hist = false;
-    int reduce = RD_NODE_REDUCE_NONE;
-    std::vector<int> devices;
-    std::vector<rd_batch *> batches;
-    std::vector<hipStream_t> streams;
-    std::vector<uint64_t *> hist_dev;          // 768 x u64 per device
-    std::vector<void *> comms;                 // ncclComm_t per device (RCCL only)
-    std::vector<std::vector<rd_frame>> share;  // the frames of the current call, per device
-};
-
-extern "C" uint32_t rd_node_batch_device_of(uint32_t n_devices, size_t frame_index)
-{
-    return n_devices ? (uint32_t)(frame_index % n_devices) : 0u;      // frame i -> GPU i mod N
-}
-
-extern "C" void rd_node_batch_destroy(rd_node_batch *nb)
-{
-    if (!nb) return;
-    for (uint32_t d = 0; d < nb->n; ++d) {
-        if (d >= nb->streams.size() || !nb->streams[d]) continue;      // nothing was set up on this entry (failed create)
-        rd_devguard g(nb->devices[d]);
-        (void)hipStreamSynchronize(nb->streams[d]);
-    }
-    if (nb->reduce == RD_NODE_REDUCE_RCCL && rd_rccl().ok)
-        for (void *c : nb->comms) if (c) (void)rd_rccl().CommDestroy(c);
-    for (uint32_t d = 0; d < nb->n; ++d) {
-        if (d < nb->batches.size()) rd_batch_destroy(nb->batches[d]);
-        const bool any = (d < nb->hist_dev.size() && nb->hist_dev[d]) || (d < nb->streams.size() && nb->streams[d]);
-        if (!any) continue;
-        rd_devguard g(nb->devices[d]);
-        if (nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
-        if (nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
-    }
-    delete nb;
-}
-
-extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
-                                    uint32_t with_histogram, rd_node_batch **out)
-{
-    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    if (!devices || !n_devices || n_devices > 64) return rd_fail(RD_ERR_INVALID_ARG, "need 1..64 devices");
-    bool dup = false;
-    for (uint32_t a = 0; a < n_devices; ++a)
-        for (uint32_t b = a + 1; b < n_devices; ++b) dup = dup || devices[a] == devices[b];
-    const char *env = getenv("RD_NODE_REDUCE");              // "host": fold on the host; "rccl": a communicator even for N = 1;
-    const bool want_host = env && !strcmp(env, "host");      // "standin": the RCCL branch over the tests' stand-in library
-    const bool want_standin = env && !strcmp(env, "standin");
-    const bool want_rccl = want_standin || (env && !strcmp(env, "rccl"));
-    // A device listed twice is a rehearsal of N > 1 on a one-GPU box: allowed only on explicit request -- the host fold, or
-    // the stand-in for librccl (real RCCL wants one rank per device).
-    if (dup && !want_host && !want_standin)
-        return rd_fail(RD_ERR_INVALID_ARG, "device list holds a device twice (RCCL wants one rank per device; RD_NODE_REDUCE=host "
-                                           "allows it for rehearsals on a one-GPU box)");
-    rd_node_batch *nb = new (std::nothrow) rd_node_batch;
-    if (!nb) return rd_fail(RD_ERR_OOM, "host allocation failed");
-    nb->n = n_devices; nb->w = width; nb->h = height; nb->fmt = format; nb->hist = with_histogram != 0;
-    nb->devices.assign(devices, devices + n_devices);
-    nb->batches.assign(n_devices, nullptr);
-    nb->streams.assign(n_devices, nullptr);
-    nb->hist_dev.assign(n_devices, nullptr);
-    nb->comms.assign(n_devices, nullptr);
-    nb->share.resize(n_devices);
-    int rc = RD_OK;
-    for (uint32_t d = 0; d < n_devices && rc == RD_OK; ++d) {
-        rc = rd_batch_create(devices[d], width, height, format, with_histogram, &nb->batches[d]);
-        if (rc) break;
-        rd_devguard g(devices[d]);
-        hipError_t e = hipStreamCreateWithFlags(&nb->streams[d], hipStreamNonBlocking);
-        if (e == hipSuccess && nb->hist) e = hipMalloc((void **)&nb->hist_dev[d], 768 * sizeof(uint64_t));
-        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "device %d: %s", devices[d], hipGetErrorString(e));
-    }
-    if (rc == RD_OK && nb->hist) {
-        if (want_host) nb->reduce = n_devices > 1 ? RD_NODE_REDUCE_HOST : RD_NODE_REDUCE_NONE;
-        else if (n_devices > 1 || want_rccl) {
-            rd_rccl_api &api = rd_rccl();
-            if (!api.ok) rc = rd_fail(RD_ERR_UNSUPPORTED, "global histogram over %u devices needs RCCL: %s", n_devices, api.error.c_str());
-            else {
-                const int r = api.CommInitAll(nb->comms.data(), (int)n_devices, nb->devices.data());
-                if (r != 0) rc = rd_fail(RD_ERR_HIP, "ncclCommInitAll: %s", api.GetErrorString(r));
-                else nb->reduce = RD_NODE_REDUCE_RCCL;
-            }
-        }
-    }
-    if (rc) { std::string keep = g_err; rd_node_batch_destroy(nb); snprintf(g_err, sizeof g_err, "%s", keep.c_str()); return rc; }
-    *out = nb;
-    return RD_OK;
-}
-
-extern "C" int rd_node_batch_set_math_mode(rd_node_batch *nb, uint32_t mode)
-{
-    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
-    for (rd_batch *b : nb->batches) { int rc = rd_batch_set_math_mode(b, mode); if (rc) return rc; }
-    return RD_OK;
-}
-
-// run fn(d) for every device, on one host thread per device when there is more than one; first error wins
-template <typename F> static int rd_node_for_each(rd_node_batch *nb, F fn)
-{
-    if (nb->n == 1) return fn(0u);
-    std::vector<int> rcs(nb->n, RD_OK);
-    std::vector<std::string> msgs(nb->n);
-    std::vector<std::thread> th;
-    th.reserve(nb->n);
-    for (uint32_t d = 0; d < nb->n; ++d)
-        th.emplace_back([&, d] { rcs[d] = fn(d); if (rcs[d]) msgs[d] = rd_last_error(); });
-    for (auto &t : th) t.join();
-    for (uint32_t d = 0; d < nb->n; ++d)
-        if (rcs[d]) return rd_fail(rcs[d], "device %d: %s", nb->devices[d], msgs[d].c_str());
-    return RD_OK;
-}
-
-extern "C" int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_frames, uint32_t row_bands)
-{
-    if (!nb || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    for (auto &v : nb->share) v.clear();
-    for (size_t i = 0; i < n_frames; ++i) nb->share[rd_node_batch_device_of(nb->n, i)].push_back(frames[i]);
-    return rd_node_for_each(nb, [&](uint32_t d) -> int {
-        const std::vector<rd_frame> &v = nb->share[d];
-        return v.empty() ? (int)RD_OK : rd_batch_develop(nb->batches[d], v.data(), v.size(), row_bands, nb->streams[d]);
-    });
-}
-
-extern "C" void *rd_node_batch_stream(rd_node_batch *nb, uint32_t index)
-{
-    return nb && index < nb->n ? (void *)nb->streams[index] : nullptr;
-}
-
-extern "C" uint32_t rd_node_batch_last_launch_count(const rd_node_batch *nb, uint32_t index)
-{
-    return nb && index < nb->n ? rd_batch_last_launch_count(nb->batches[index]) : 0u;
-}
-
-extern "C" int rd_node_batch_reduce_kind(const rd_node_batch *nb) { return nb ? nb->reduce : -1; }
-
-// test hook: what devices[index]'s 768 x u64 buffer holds after the last rd_node_batch_histogram (after an all-reduce
-// every device must hold the global sum, not only the one the call reads back)
-extern "C" int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768])
-{
-    if (!nb || !hist || index >= nb->n || !nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "rd_debug_node_histogram_of: bad argument");
-    rd_devguard g(nb->devices[index]);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[index]);
-    RD_HIP(hipMemcpyAsync(hist, nb->hist_dev[index], 768 * sizeof(uint64_t), hipMemcpyDeviceToHost, nb->streams[index]));
-    RD_HIP(hipStreamSynchronize(nb->streams[index]));
-    return RD_OK;
-}
-
-extern "C" int rd_node_batch_synchronize(rd_node_batch *nb)
-{
-    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
-    for (uint32_t d = 0; d < nb->n; ++d) {
-        rd_devguard g(nb->devices[d]);
-        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
-        RD_HIP(hipStreamSynchronize(nb->streams[d]));
-    }
-    return RD_OK;
-}
-
-extern "C" int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768])
-{
-    if (!nb || !hist) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
-    // per-device fold of the slabs into 768 x u64, on each device's stream (after the launches enqueued there)
-    for (uint32_t d = 0; d < nb->n; ++d) {
-        int rc = rd_batch_histogram(nb->batches[d], nb->hist_dev[d], nb->streams[d]);
-        if (rc) return rc;
-    }
-    if (nb->reduce == RD_NODE_REDUCE_RCCL) {                  // one in-place all-reduce of 6 KiB per device, grouped
-        rd_rccl_api &api = rd_rccl();
-        int r = api.GroupStart();
-        for (uint32_t d = 0; d < nb->n && r == 0; ++d) {
-            rd_devguard g(nb->devices[d]);
-            r = api.AllReduce(nb->hist_dev[d], nb->hist_dev[d], 768, RD_NCCL_UINT64, RD_NCCL_SUM, nb->comms[d], nb->streams[d]);
-        }
-        const int r2 = api.GroupEnd();
-        if (r == 0) r = r2;
-        if (r != 0) return rd_fail(RD_ERR_HIP, "ncclAllReduce: %s", api.GetErrorString(r));
-    }
-    const uint32_t take = nb->reduce == RD_NODE_REDUCE_HOST ? nb->n : 1u;      // after an all-reduce every device holds the sum
-    uint64_t part[768];
-    memset(hist, 0, 768 * sizeof(uint64_t));
-    for (uint32_t d = 0; d < take; ++d) {
-        rd_devguard g(nb->devices[d]);
-        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
-        RD_HIP(hipMemcpyAsync(part, nb->hist_dev[d], sizeof part, hipMemcpyDeviceToHost, nb->streams[d]));
-        RD_HIP(hipStreamSynchronize(nb->streams[d]));
-        for (int k = 0; k < 768; ++k) hist[k] += part[k];
-    }
-    return rd_node_batch_synchronize(nb);                      // the call returns with every device's work done
-}
-
-// ------------------------------------------------------------------------------------------------
-// rd_exporter: develop -> HBM slot -> pinned host slot, copy stream overlapping the compute stream
-// ------------------------------------------------------------------------------------------------
-struct rd_export_slot {
-    void *dev = nullptr;
-    void *host = nullptr;
-    hipEvent_t kernel_done = nullptr, copy_done = nullptr;
-    bool busy = false, used = false;
-};
-
-struct rd_exporter {
-    int device = 0;
-    uint32_t w = 0, h = 0, fmt = 0, math_mode = RD_MATH_STRICT, n_slots = 0, next = 0;
-    size_t bytes = 0;
-    rd_launch_cfg cfg;
-    hipStream_t compute = nullptr, copy = nullptr;
-    rd_export_slot *slots = nullptr;
-    rd_scratch scratch;
-    std::mutex mu;
-};
-
-extern "C" void rd_exporter_destroy(rd_exporter *e)
-{
-    if (!e) return;
-    {
-        rd_devguard g(e->device);
-        if (e->compute) (void)hipStreamSynchronize(e->compute);
-        if (e->copy) (void)hipStreamSynchronize(e->copy);
-        for (uint32_t i = 0; e->slots && i < e->n_slots; ++i) {
-            if (e->slots[i].dev) (void)hipFree(e->slots[i].dev);
-            if (e->slots[i].host) (void)hipHostFree(e->slots[i].host);
-            if (e->slots[i].kernel_done) (void)hipEventDestroy(e->slots[i].kernel_done);
-            if (e->slots[i].copy_done) (void)hipEventDestroy(e->slots[i].copy_done);
-        }
-        if (e->compute) (void)hipStreamDestroy(e->compute);
-        if (e->copy) (void)hipStreamDestroy(e->copy);
-        e->scratch.release();
-    }
-    delete[] e->slots;
-    delete e;
-}
-
-extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t math_mode, uint32_t n_slots,
-                                  rd_exporter **out)
-{
-    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    if (!w || !h || !n_slots || n_slots > 64) return rd_fail(RD_ERR_INVALID_ARG, "bad frame size or slot count");
-    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "export needs an even frame width (got %u)", w);
-    const size_t bpp = rd_format_bytes_per_pixel(fmt);
-    if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 export needs width %% 128 == 0 (got %u)", w);
-    if (math_mode != RD_MATH_STRICT && math_mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", math_mode);
-    if (!(rd_identity_map(w) && rd_identity_map(h))) return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h);
-    int n_cu = 0;
-    int rc = rd_check_device(device, &n_cu);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    rc = rd_q8_lut_ensure(device);
-    if (rc) return rc;
-    rd_exporter *e = new (std::nothrow) rd_exporter;
-    if (!e) return rd_fail(RD_ERR_OOM, "host allocation failed");
-    e->device = device; e->w = w; e->h = h; e->fmt = fmt; e->math_mode = math_mode; e->n_slots = n_slots;
-    e->bytes = (size_t)w * h * bpp;
-    e->cfg.n_cu = n_cu;
-    e->slots = new (std::nothrow) rd_export_slot[n_slots];
-    hipError_t err = e->slots ? hipSuccess : hipErrorOutOfMemory;
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
-    for (uint32_t i = 0; err == hipSuccess && i < n_slots; ++i) {
-        err = hipMalloc(&e->slots[i].dev, e->bytes);
-        if (err == hipSuccess) err = hipHostMalloc(&e->slots[i].host, e->bytes, hipHostMallocDefault);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].kernel_done, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].copy_done, hipEventDisableTiming);
-    }
-    if (err != hipSuccess) {
-        int code = rd_fail(err == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "exporter setup failed: %s", hipGetErrorString(err));
-        rd_exporter_destroy(e);
-        return code;
-    }
-    *out = e;
-    return RD_OK;
-}
-
-extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out)
-{
-    if (!e || !fr || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (!fr->cfa_dev || ((uintptr_t)fr->cfa_dev % 4u)) return rd_fail(RD_ERR_INVALID_ARG, "cfa_dev NULL or not 4-byte aligned");
-    rd_devguard g(e->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
-    std::lock_guard<std::mutex> lk(e->mu);
-    const uint32_t si = e->next;
-    rd_export_slot &s = e->slots[si];
-    if (s.busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u has not been released (ring of %u full)", si, e->n_slots);
-    // the previous copy out of this HBM slot must have finished before the kernel overwrites it
-    if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
-    if (fr->matrix_layout != RD_MATRIX_REFERENCE && fr->matrix_layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", fr->matrix_layout);
-    const rd_ku u = rd_frame_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode, fr->matrix_layout);
-    const rd_scratch::lease l = e->scratch.get(e->compute, false);
-    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
-                               e->math_mode, nullptr, nullptr, 0, l.tq, e->compute, nullptr);
-    e->scratch.used(l, e->compute, rc != RD_OK);
-    if (rc) return rc;
-    RD_HIP(hipEventRecord(s.kernel_done, e->compute));
-    RD_HIP(hipStreamWaitEvent(e->copy, s.kernel_done, 0));
-    RD_HIP(hipMemcpyAsync(s.host, s.dev, e->bytes, hipMemcpyDeviceToHost, e->copy));
-    RD_HIP(hipEventRecord(s.copy_done, e->copy));
-    s.busy = true; s.used = true;
-    e->next = (si + 1u) % e->n_slots;
-    *slot_out = si;
-    return RD_OK;
-}
-
-extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len)
-{
-    if (!e || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
-    rd_devguard g(e->device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
-    hipEvent_t ev;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        if (!e->slots[slot].busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u holds no frame", slot);
-        ev = e->slots[slot].copy_done;
-    }
-    RD_HIP(hipEventSynchronize(ev));
-    *data = e->slots[slot].host;
-    if (len) *len = e->bytes;
-    return RD_OK;
-}
-
-extern "C" int rd_exporter_release(rd_exporter *e, uint32_t slot)
-{
-    if (!e) return rd_fail(RD_ERR_INVALID_ARG, "NULL exporter");
-    if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
-    std::lock_guard<std::mutex> lk(e->mu);
-    e->slots[slot].busy = false;
-    return RD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// self-test of the 8-bit surfaces' gamma shortcut (rd_kernels.h, rd_q8_gamma) over every float encoding
-// ------------------------------------------------------------------------------------------------
-struct rd_q8_stats { unsigned long long mismatches, fallbacks; uint32_t first_bad, max_dist_bits; };
-
-__global__ void __launch_bounds__(256) rd_q8_sweep(uint32_t base, rd_q8_stats *st, uint8_t *codes)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float x = rd_u2f(base + i);
-    const uint32_t fast = rd_q8_gamma(x);
-    const uint32_t exact = rd_q8(rd_gamma_clamp(x));
-    if (codes) codes[i] = (uint8_t)fast;
-    if (!st) return;
-    if (fast != exact || fast > 255u) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
-    if (x >= RD_FLT_MIN) {                                       // diagnostics: how often the pinned evaluation decides, and how far
-        float z;                                                 // the hardware 255 e is from the pinned 255 g (in codes)
-        const float e = rd_hw_gamma01(x, z);
-        const float t = __builtin_fmaf(e, 255.0f, RD_MAGIC23);
-        const float dn = __builtin_fmaf(e, 255.0f, -(t - RD_MAGIC23));
-        if (__builtin_fabsf(dn) > 0.5f - RD_Q8_EPS) atomicAdd(&st->fallbacks, 1ull);
-        const float d = __builtin_fabsf(e * 255.0f - rd_gamma_clamp(x) * 255.0f);
-        atomicMax(&st->max_dist_bits, rd_f2u(d));               // d >= 0: integer order == float order
-    }
-}
-
-extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks, float *max_dist)
-{
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
-    RD_HIP(hipMalloc((void **)&dst, sizeof st));
-    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
-    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {    // 256 launches x 2^24 encodings
-        hipLaunchKernelGGL(rd_q8_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint8_t *)nullptr);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
-    (void)hipFree(dst);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8: %s", hipGetErrorString(e));
-    if (mismatches) *mismatches = st.mismatches;
-    if (first_bad) *first_bad = st.first_bad;
-    if (fallbacks) *fallbacks = st.fallbacks;
-    if (max_dist) *max_dist = rd_u2f(st.max_dist_bits);
-    return RD_OK;
-}
-
-// The export kernel's threshold table (rd_q8_lut_bits) against the pinned evaluation, same sweep: the table in LDS, as there.
-__global__ void __launch_bounds__(256) rd_q8_lut_sweep(uint32_t base, rd_q8_stats *st, uint8_t *codes)
-{
-    __shared__ uint32_t lut[RD_Q8_LUT_WORDS];
-    rd_q8_lut_load(lut);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float x = rd_u2f(base + i);
-    const uint32_t sbits = rd_q8_lut_bits(x, lut);
-    const uint32_t fast = sbits >> 16;                           // bits 24..31 must be zero: compared as a whole
-    const uint32_t exact = rd_q8(rd_gamma_clamp(x));
-    if (codes) codes[i] = (uint8_t)fast;
-    if (!st) return;
-    if (fast != exact) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
-}
-
-extern "C" int rd_selftest_q8_lut(int device, uint64_t *mismatches, uint32_t *first_bad)
-{
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    rc = rd_q8_lut_ensure(device);
-    if (rc) return rc;
-    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
-    RD_HIP(hipMalloc((void **)&dst, sizeof st));
-    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
-    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {    // 256 launches x 2^24 encodings
-        hipLaunchKernelGGL(rd_q8_lut_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint8_t *)nullptr);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
-    (void)hipFree(dst);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_lut: %s", hipGetErrorString(e));
-    if (mismatches) *mismatches = st.mismatches;
-    if (first_bad) *first_bad = st.first_bad;
-    return RD_OK;
-}
-
-extern "C" int rd_selftest_q8_lut_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
-{
-    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
-        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_q8_lut_codes: n must be a non-zero multiple of 256 inside the 2^32 encodings");
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    rc = rd_q8_lut_ensure(device);
-    if (rc) return rc;
-    uint8_t *dev = nullptr;
-    RD_HIP(hipMalloc((void **)&dev, n));
-    hipLaunchKernelGGL(rd_q8_lut_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpy(dst, dev, n, hipMemcpyDeviceToHost);
-    (void)hipFree(dev);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_lut_codes: %s", hipGetErrorString(e));
-    return RD_OK;
-}
-
-// No device needed: the table itself (RD_Q8_LUT_WORDS words), for host-side checks of its construction.
-extern "C" int rd_q8_lut_table(uint32_t *dst, size_t cap_words)
-{
-    if (!dst || cap_words < RD_Q8_LUT_WORDS) return rd_fail(RD_ERR_INVALID_ARG, "rd_q8_lut_table: need room for %u words", RD_Q8_LUT_WORDS);
-    rd_q8_lut_build(dst);
-    return (int)RD_Q8_LUT_WORDS;
-}
-
-// The same for the binary16 surface's shortcut (rd_f16_gamma): halves and, with the histogram, codes.
-__global__ void __launch_bounds__(256) rd_f16_sweep(uint32_t base, rd_q8_stats *st, uint16_t *halves)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float x = rd_u2f(base + i);
-    uint32_t h, q, h2, q2;
-    rd_f16_gamma<true>(x, h, q);
-    rd_f16_gamma<false>(x, h2, q2);                          // the variant without the histogram must give the same half
-    const float g = rd_gamma_clamp(x);
-    const uint32_t he = __builtin_bit_cast(uint16_t, (_Float16)g), qe = rd_q8(g);
-    if (halves) halves[i] = (uint16_t)h;
-    if (!st) return;
-    if (h != he || q != qe || h2 != he) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
-    if (x >= RD_FLT_MIN) {                                    // how often the pinned evaluation decides the half
-        const float z = __builtin_amdgcn_logf(x) * RD_INV_GAMMA;
-        const float e = __builtin_fminf(__builtin_amdgcn_exp2f(z), 1.0f);
-        const float lowbits = rd_u2f((rd_f2u(e) & 0x1fffu) | 0x4b000000u) - 8388608.0f;
-        const float k = __builtin_fmaf(__builtin_fabsf(z), RD_F16_KA, RD_F16_KB);
-        if (e >= 6.103515625e-05f && __builtin_fabsf(lowbits - 4096.0f) <= k) atomicAdd(&st->fallbacks, 1ull);   // normal halves only
-    }
-}
-
-extern "C" int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks)
-{
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
-    RD_HIP(hipMalloc((void **)&dst, sizeof st));
-    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
-    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {
-        hipLaunchKernelGGL(rd_f16_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint16_t *)nullptr);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
-    (void)hipFree(dst);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16: %s", hipGetErrorString(e));
-    if (mismatches) *mismatches = st.mismatches;
-    if (first_bad) *first_bad = st.first_bad;
-    if (fallbacks) *fallbacks = st.fallbacks;
-    return RD_OK;
-}
-
-extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst)
-{
-    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
-        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_f16_halves: n must be a non-zero multiple of 256 inside the 2^32 encodings");
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    uint16_t *dev = nullptr;
-    RD_HIP(hipMalloc((void **)&dev, (size_t)n * 2));
-    hipLaunchKernelGGL(rd_f16_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpy(dst, dev, (size_t)n * 2, hipMemcpyDeviceToHost);
-    (void)hipFree(dev);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16_halves: %s", hipGetErrorString(e));
-    return RD_OK;
-}
-
-extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
-{
-    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
-        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_q8_codes: n must be a non-zero multiple of 256 inside the 2^32 encodings");
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    uint8_t *dev = nullptr;
-    RD_HIP(hipMalloc((void **)&dev, n));
-    hipLaunchKernelGGL(rd_q8_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpy(dst, dev, n, hipMemcpyDeviceToHost);
-    (void)hipFree(dev);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_codes: %s", hipGetErrorString(e));
-    return RD_OK;
-}
+#include "rd_host_pipeline.inl"
+#include "rd_host_batch.inl"
+#include "rd_host_diag.inl"
 
 // ------------------------------------------------------------------------------------------------
 // ingest helper: lossless-JPEG tiles of compressed DNGs (host code; rd_ljpeg.h)
@@ -2111,178 +474,6 @@ extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, si
     case rd_ljpeg::ERR_TRUNCATED: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: lossless-JPEG stream is truncated");
     default: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: malformed lossless-JPEG stream");
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// measurement aid: the streaming ceilings of THIS device, now (bench.py: roofline.box_copy_GBps / box_fill_GBps)
-// ------------------------------------------------------------------------------------------------
-// Boxes of one pool differ by a few per cent (power-managed clocks), and SURVEY.md section 8d asks for the roofline
-// fraction against a ceiling measured on the box, not only against the 8 TB/s of the data sheet.  Three trivial kernels,
-// 16 B per lane and access, eight accesses in flight per lane; a WAVE walks its own contiguous range (1 KiB per
-// instruction, 8 KiB per step).  That shape is the fastest of the ones tools/hbm_probe.hip tries (profiles/r04_hbm_probe.txt:
-// copy 5.72 TB/s, fill 6.11 TB/s against 4.9 / 4.9 TB/s for a grid-stride loop with the same accesses in flight and
-// 5.0 / 4.2 TB/s for the one-access grid-stride loop this function started with); hipMemsetAsync is reported beside them.
-#define RD_PROBE_U 8
-__global__ void __launch_bounds__(1024) rd_probe_copy(const rd_f4 *__restrict__ src, rd_f4 *__restrict__ dst, size_t per_wave)
-{
-    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for (size_t i = w * per_wave; i < (w + 1) * per_wave; i += 64u * RD_PROBE_U) {
-        rd_f4 v[RD_PROBE_U];
-#pragma unroll
-        for (int k = 0; k < RD_PROBE_U; ++k) v[k] = src[i + (size_t)k * 64u + lane];
-#pragma unroll
-        for (int k = 0; k < RD_PROBE_U; ++k) __builtin_nontemporal_store(v[k], dst + i + (size_t)k * 64u + lane);
-    }
-}
-
-__global__ void __launch_bounds__(1024) rd_probe_fill(rd_f4 *__restrict__ dst, size_t per_wave, float x)
-{
-    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const rd_f4 v = { x, x + 1.0f, x + 2.0f, 1.0f };
-    for (size_t i = w * per_wave; i < (w + 1) * per_wave; i += 64u * RD_PROBE_U) {
-#pragma unroll
-        for (int k = 0; k < RD_PROBE_U; ++k) __builtin_nontemporal_store(v, dst + i + (size_t)k * 64u + lane);
-    }
-}
-
-__global__ void __launch_bounds__(1024) rd_probe_read(const rd_f4 *__restrict__ src, size_t per_wave, float *sink)
-{
-    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    float acc = 0.0f;
-    for (size_t i = w * per_wave; i < (w + 1) * per_wave; i += 64u * RD_PROBE_U) {
-        rd_f4 v[RD_PROBE_U];
-#pragma unroll
-        for (int k = 0; k < RD_PROBE_U; ++k) v[k] = src[i + (size_t)k * 64u + lane];
-#pragma unroll
-        for (int k = 0; k < RD_PROBE_U; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
-    }
-    if (acc == 12345.678f) *sink = acc;                      // never true for the zeroed buffer: keeps the loads alive
-}
-
-extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
-                              double *memset_GBps)
-{
-    if (bytes < ((size_t)64 << 20) || !reps || reps > 64) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need >= 64 MiB and 1..64 repetitions");
-    int rc = rd_check_device(device, nullptr);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    // copy: 4096 x 16 waves, fill / read: 2048 x 16 waves; every wave owns a whole number of 8-KiB steps
-    const uint32_t blocks[3] = { 4096u, 2048u, 2048u };
-    const size_t step = 64u * RD_PROBE_U;                                        // float4 per wave and step
-    const size_t per_wave_max = bytes / sizeof(rd_f4) / (2048u * 16u) / step * step;
-    const size_t n = per_wave_max * 2048u * 16u;                                  // float4 actually moved (both grids divide it)
-    void *a = nullptr, *b = nullptr;
-    float *sink = nullptr;
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipMalloc(&a, n * sizeof(rd_f4));
-    if (e == hipSuccess) e = hipMalloc(&b, n * sizeof(rd_f4));
-    if (e == hipSuccess) e = hipMalloc((void **)&sink, sizeof(float));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * sizeof(rd_f4), s);
-    if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(rd_f4), s);
-    double out[4] = { 0.0, 0.0, 0.0, 0.0 };
-    for (int which = 0; which < 4 && e == hipSuccess; ++which) {
-        std::vector<float> ms;
-        const size_t per_wave = which < 3 ? n / ((size_t)blocks[which] * 16u) : 0;
-        for (uint32_t r = 0; r < reps + 1u && e == hipSuccess; ++r) {             // the first launch warms up
-            e = hipEventRecord(e0, s);
-            if (which == 0) hipLaunchKernelGGL(rd_probe_copy, dim3(blocks[0]), dim3(1024), 0, s, (const rd_f4 *)a, (rd_f4 *)b, per_wave);
-            else if (which == 1) hipLaunchKernelGGL(rd_probe_fill, dim3(blocks[1]), dim3(1024), 0, s, (rd_f4 *)b, per_wave, (float)r);
-            else if (which == 2) hipLaunchKernelGGL(rd_probe_read, dim3(blocks[2]), dim3(1024), 0, s, (const rd_f4 *)a, per_wave, sink);
-            else if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(rd_f4), s);
-            if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipEventRecord(e1, s);
-            if (e == hipSuccess) e = hipEventSynchronize(e1);
-            float t = 0.0f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
-            if (e == hipSuccess && r) ms.push_back(t);
-        }
-        if (e == hipSuccess) {
-            std::sort(ms.begin(), ms.end());
-            const double med = ms[ms.size() / 2];
-            out[which] = (which == 0 ? 2.0 : 1.0) * (double)(n * sizeof(rd_f4)) / (med * 1e-3) / 1e9;
-        }
-    }
-    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    if (sink) (void)hipFree(sink);
-    if (e != hipSuccess) return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "rd_measure_hbm: %s", hipGetErrorString(e));
-    if (copy_GBps) *copy_GBps = out[0];
-    if (fill_GBps) *fill_GBps = out[1];
-    if (read_GBps) *read_GBps = out[2];
-    if (memset_GBps) *memset_GBps = out[3];
-    return RD_OK;
-}
-
-// What one full-rate VALU wave-instruction costs a SIMD on THIS device right now: 512 x 1024 threads (8 waves per SIMD, as
-// the export kernel runs), eight independent chains per lane of alternating v_mul_f32 / v_add_f32 -- the two-operand forms
-// the strict colour stack is made of (tools/valu_probe2.hip: 1.05 ns per instruction for this pair, 1.20 ns for the
-// three-operand v_fma_f32; the cheaper one is the honest price for a LOWER bound on issue time).  bench.py prices the
-// export kernels' static instruction budgets (profiles/isa_budget.json, in units of half such an instruction) with it.
-__global__ void __launch_bounds__(1024) rd_probe_valu(float *out, float a, float b, int iters)
-{
-    float av = a, bv = b, x[8];
-    asm volatile("" : "+v"(av), "+v"(bv));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = (float)(threadIdx.x + i) * 1e-3f;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (r & 1) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(bv));
-                else asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(av));
-            }
-    }
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += x[i];
-    if (s == 1234.5678f) out[0] = s;
-}
-
-extern "C" int rd_measure_valu(int device, double *ns_per_full_rate_instruction)
-{
-    if (!ns_per_full_rate_instruction) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_valu: NULL argument");
-    int n_cu = 0;
-    int rc = rd_check_device(device, &n_cu);
-    if (rc) return rc;
-    rd_devguard g(device);
-    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    const int iters = 512, blocks = 2 * n_cu;                                   // two 1024-thread workgroups per CU
-    float *out = nullptr;
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipMalloc((void **)&out, 64);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    std::vector<float> ms;
-    for (int r = 0; r < 6 && e == hipSuccess; ++r) {
-        e = hipEventRecord(e0, s);
-        hipLaunchKernelGGL(rd_probe_valu, dim3(blocks), dim3(1024), 0, s, out, 0.999f, 0.001f, iters);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(e1, s);
-        if (e == hipSuccess) e = hipEventSynchronize(e1);
-        float t = 0.0f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
-        if (e == hipSuccess && r) ms.push_back(t);
-    }
-    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (out) (void)hipFree(out);
-    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_measure_valu: %s", hipGetErrorString(e));
-    std::sort(ms.begin(), ms.end());
-    const double per_simd = (double)blocks * 16.0 * 8.0 * 4.0 * iters / ((double)n_cu * 4.0);     // wave-instructions each SIMD issued
-    *ns_per_full_rate_instruction = ms.front() * 1e6 / per_simd;      // the fastest of five: the clock the part reaches under pure VALU load
-    return RD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,723 @@
+// rd_host_batch.inl -- part of librawdev.so's host side: included by rawdev.hip (one translation unit; the kernels are
+// templates in rd_kernels.h).  rd_batch (multi-frame launches), rd_node_batch (one process, N devices, RCCL histogram all-reduce), rd_exporter
+// (pinned ring): the batch export the north-star adds (BASELINE.json configs 3-5; no reference counterpart).
+
+// ------------------------------------------------------------------------------------------------
+// rd_batch
+// ------------------------------------------------------------------------------------------------
+struct rd_batch {
+    int device = 0;
+    uint32_t w = 0, h = 0, fmt = 0;
+    bool hist = false;
+    bool identity_ok = false;
+    uint32_t math_mode = RD_MATH_STRICT;
+    rd_launch_cfg cfg;
+    uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
+    // RD_BATCH_STREAMS=2: launches alternate between the caller's stream and an internal one (forked from and joined back
+    // into the caller's stream inside rd_batch_develop), so the next frame's workgroups move in as the previous frame's
+    // finish.  Concurrent launches need their own slab rows and ticket counters.  Measured +2.4 % (strict) / -2 %
+    // (contracted) on 256 x 24 MP: not the default.
+    uint32_t n_streams = 1;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long *slab64 = nullptr;      // n_streams x blocks x 768
+    rd_scratch scratch;                        // per stream: ticket counters
+    // Multi-frame launches (the default; RD_BATCH_PERSISTENT=0 falls back to one launch per frame / row band): the
+    // frames of a call reach the kernel as an array of descriptors in HBM.  Two arrays with pinned staging; an array is
+    // rewritten only when the caller's frames differ from what it holds (bench.py re-submits the same batch every
+    // step), and only after the launches that read it have finished (`done`).
+    bool persistent = true;
+    uint32_t max_frames = 8;                   // RD_BATCH_MAX_FRAMES: frames per launch (default 8 for f32, 32 otherwise)
+    struct desc_buf {
+        rd_frame_desc *dev = nullptr, *host = nullptr;
+        size_t cap = 0, n = 0;
+        hipEvent_t done = nullptr;             // after the last launch that reads the array
+        hipEvent_t uploaded = nullptr;         // after the copy that filled it (a later call may come on another stream)
+        bool valid = false;
+    } db[2];
+    int db_last = 1;
+    uint32_t last_launches = 0;                // fused launches enqueued by the last rd_batch_develop call
+};
+
+extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
+                               rd_batch **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
+    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
+    if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs width %% 128 == 0 (got %u)", w);
+    const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
+    if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
+    int n_cu = 0;
+    int rc = rd_check_device(device, &n_cu);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
+    rd_batch *b = new (std::nothrow) rd_batch;
+    if (!b) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    b->device = device; b->w = w; b->h = h; b->fmt = fmt; b->hist = with_histogram != 0;
+    b->cfg.n_cu = n_cu;
+    b->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
+    b->cfg.wg_per_cu_hist = rd_env_u32("RD_WG_PER_CU_HIST", 2);      // experiment builds with a smaller RD_BLOCK only
+    b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
+    if (!b->identity_ok) { delete b; return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h); }
+    b->blocks = rd_blocks_for(b->cfg, items, b->hist);
+    b->n_streams = rd_env_u32("RD_BATCH_STREAMS", 1) >= 2 ? 2u : 1u;
+    {
+        const char *pe = getenv("RD_BATCH_PERSISTENT");
+        b->persistent = !(pe && *pe == '0') && b->n_streams == 1;
+        // f32: 8 is the flat bottom of the curve; the narrow surfaces are arithmetic-bound and only
+        // lose launch tails as launches grow (u8 48.7 / 48.6 / 48.2, f16 61.2 / 60.6 / 60.2 us per frame at 8 / 16 / 32)
+        b->max_frames = rd_env_u32("RD_BATCH_MAX_FRAMES", fmt == RD_FMT_RGBA_F32 ? 8u : 32u);
+    }
+    hipError_t e = hipSuccess;
+    for (int j = 0; j < 2 && e == hipSuccess && b->persistent; ++j) {
+        e = hipEventCreateWithFlags(&b->db[j].done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->db[j].uploaded, hipEventDisableTiming);
+    }
+    if (b->n_streams > 1) {
+        e = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+    }
+    if (e == hipSuccess && b->hist) {
+        const size_t bytes = (size_t)b->n_streams * b->blocks * 768 * sizeof(unsigned long long);
+        e = hipMalloc((void **)&b->slab64, bytes);
+        if (e == hipSuccess) e = hipMemset(b->slab64, 0, bytes);
+    }
+    if (e != hipSuccess) {
+        const int code = rd_fail(RD_ERR_OOM, "batch resources: %s", hipGetErrorString(e));
+        rd_batch_destroy(b);
+        return code;
+    }
+    *out = b;
+    return RD_OK;
+}
+
+extern "C" void rd_batch_destroy(rd_batch *b)
+{
+    if (!b) return;
+    {
+        rd_devguard g(b->device);
+        (void)hipDeviceSynchronize();        // launches on the caller's streams still use the slab and the tickets
+        if (b->slab64) (void)hipFree(b->slab64);
+        b->scratch.release();
+        for (auto &d : b->db) {
+            if (d.dev) (void)hipFree(d.dev);
+            if (d.host) (void)hipHostFree(d.host);
+            if (d.done) (void)hipEventDestroy(d.done);
+            if (d.uploaded) (void)hipEventDestroy(d.uploaded);
+        }
+        if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+        if (b->aux) (void)hipStreamDestroy(b->aux);
+    }
+    delete b;
+}
+
+extern "C" int rd_batch_set_math_mode(rd_batch *b, uint32_t mode)
+{
+    if (!b) return rd_fail(RD_ERR_INVALID_ARG, "NULL batch");
+    if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
+    b->math_mode = mode;
+    return RD_OK;
+}
+
+// How many frames one multi-frame launch may hold for frames of w x h: the 32-bit tile index, the u32 histogram bins a
+// workgroup keeps in LDS for the whole launch (every pixel of the launch could, in principle, land in one bin of one
+// workgroup), and the per-format default / RD_BATCH_MAX_FRAMES cap.
+static uint64_t rd_frames_per_launch_limit(uint32_t w, uint32_t h, bool hist, uint32_t cap)
+{
+    const uint32_t tpu = ((w >> 1) + 63u) / 64u;
+    const uint64_t tpf = (uint64_t)(h / 2u + 1u) * tpu;
+    uint64_t kmax = 0xfffffffeull / tpf;
+    if (hist) { const uint64_t k2 = 0xffffffffull / ((uint64_t)w * h); if (k2 < kmax) kmax = k2; }
+    if (kmax > 4096) kmax = 4096;
+    if (cap && cap < kmax) kmax = cap;
+    return kmax < 1 ? 1 : kmax;
+}
+
+// Frames of the next launch, starting at frame i0: as many consecutive frames as the limit allows whose surfaces
+// ([out, out + surf_bytes)) overlap none of the launch's earlier ones.
+static size_t rd_next_launch_size(const rd_frame *frames, size_t n, size_t i0, size_t surf_bytes, uint64_t kmax)
+{
+    size_t c = 1;
+    for (; i0 + c < n && c < kmax; ++c) {
+        const uintptr_t o = (uintptr_t)frames[i0 + c].out_dev;
+        bool clash = false;
+        for (size_t k = 0; k < c && !clash; ++k) {
+            const uintptr_t p = (uintptr_t)frames[i0 + k].out_dev;
+            clash = o < p + surf_bytes && p < o + surf_bytes;
+        }
+        if (clash) break;
+    }
+    return c;
+}
+
+// No device needed: the launches rd_batch_develop would cut a call into (frames per launch, in order).  Returns the number
+// of launches, or a negative rd_status; at most `counts_cap` entries are written.
+extern "C" int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t format, uint32_t with_histogram,
+                                      const rd_frame *frames, size_t n_frames, uint32_t max_frames, uint32_t *counts,
+                                      size_t counts_cap)
+{
+    const size_t bpp = rd_format_bytes_per_pixel(format);
+    if (!width || !height || !bpp || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "rd_batch_plan_launches: bad argument");
+    const uint32_t cap = max_frames ? max_frames : (format == RD_FMT_RGBA_F32 ? 8u : 32u);
+    const uint64_t kmax = rd_frames_per_launch_limit(width, height, with_histogram != 0, cap);
+    const size_t surf = (size_t)width * height * bpp;
+    int launches = 0;
+    for (size_t i0 = 0; i0 < n_frames;) {
+        const size_t c = rd_next_launch_size(frames, n_frames, i0, surf, kmax);
+        if (counts && (size_t)launches < counts_cap) counts[launches] = (uint32_t)c;
+        ++launches;
+        i0 += c;
+    }
+    return launches;
+}
+
+// The multi-frame path of rd_batch_develop: descriptors -> HBM (only when they changed), then as few launches as the
+// limits allow.  A launch never holds two frames whose surfaces overlap (the order in which the tiles of DIFFERENT frames
+// are stored inside one launch is not defined), never more pixels than a u32 histogram bin can count, and never more
+// tiles than the 32-bit tile index.  Row bands need no launches of their own here: the ticket front sweeps a frame in
+// row order, so a "band" is a range of tickets.
+static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n, hipStream_t s)
+{
+    if (!n) return RD_OK;
+    const size_t bpp = rd_format_bytes_per_pixel(b->fmt);
+    const size_t surf_bytes = (size_t)b->w * b->h * bpp;
+    static thread_local std::vector<rd_frame_desc> tmp;
+    tmp.resize(n);
+    memset(tmp.data(), 0, n * sizeof(rd_frame_desc));
+    bool aligned16 = true;
+    for (size_t f = 0; f < n; ++f) {
+        const rd_frame &fr = frames[f];
+        if (!fr.cfa_dev || !fr.out_dev) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f);
+        if ((uintptr_t)fr.cfa_dev % 4u) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f);
+        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f);
+        if ((uintptr_t)fr.cfa_dev % 16u) aligned16 = false;
+        tmp[f].cfa = fr.cfa_dev;
+        tmp[f].out = fr.out_dev;
+        if (fr.matrix_layout != RD_MATRIX_REFERENCE && fr.matrix_layout != RD_MATRIX_ROW_MAJOR)
+            return rd_fail(RD_ERR_INVALID_ARG, "frame %zu: unknown matrix layout %u", f, fr.matrix_layout);
+        tmp[f].u = rd_frame_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level, b->math_mode, fr.matrix_layout);
+        static const bool no_elide = rd_env_u32("RD_NO_ELIDE", 0) != 0;
+        if (no_elide) tmp[f].u.elide = 0u;
+    }
+    // descriptor array in HBM: reuse, or rewrite the one not used by the previous call
+    int j = -1;
+    for (int k = 0; k < 2; ++k)
+        if (b->db[k].valid && b->db[k].n == n && memcmp(b->db[k].host, tmp.data(), n * sizeof(rd_frame_desc)) == 0) j = k;
+    if (j < 0) {
+        j = b->db_last ^ 1;
+        rd_batch::desc_buf &d = b->db[j];
+        RD_HIP(hipEventSynchronize(d.done));                 // launches that read this array (two calls ago) have finished
+        d.valid = false;
+        if (d.cap < n) {
+            if (d.dev) { (void)hipFree(d.dev); d.dev = nullptr; }
+            if (d.host) { (void)hipHostFree(d.host); d.host = nullptr; }
+            d.cap = 0;
+            const size_t cap = n < 64 ? 64 : n;
+            RD_HIP(hipMalloc((void **)&d.dev, cap * sizeof(rd_frame_desc)));
+            RD_HIP(hipHostMalloc((void **)&d.host, cap * sizeof(rd_frame_desc), hipHostMallocDefault));
+            d.cap = cap;
+        }
+        memcpy(d.host, tmp.data(), n * sizeof(rd_frame_desc));
+        RD_HIP(hipMemcpyAsync(d.dev, d.host, n * sizeof(rd_frame_desc), hipMemcpyHostToDevice, s));
+        RD_HIP(hipEventRecord(d.uploaded, s));
+        d.n = n;
+        d.valid = true;
+    } else {
+        RD_HIP(hipStreamWaitEvent(s, b->db[j].uploaded, 0));     // reused array: its copy may have been enqueued on another stream
+    }
+    b->db_last = j;
+    const rd_frame_desc *descs = b->db[j].dev;
+
+    const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->hist, b->max_frames);
+    const rd_scratch::lease l = b->scratch.get(s, false);
+    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    uint32_t *tq = l.tq;
+    int rc = RD_OK;
+    b->last_launches = 0;
+    (void)hipGetLastError();                     // see rd_enqueue_render
+    for (size_t i0 = 0; i0 < n && rc == RD_OK;) {
+        const size_t c = rd_next_launch_size(frames, n, i0, surf_bytes, kmax);
+        RD_DISPATCH(rd_launch_batch_t, b->fmt, b->hist, b->math_mode, descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16,
+                    b->slab64, tq, s);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "multi-frame launch failed: %s", hipGetErrorString(e));
+        else b->last_launches += 1;
+        i0 += c;
+    }
+    b->scratch.used(l, s, rc != RD_OK);
+    RD_HIP(hipEventRecord(b->db[j].done, s));
+    return rc;
+}
+
+extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, uint32_t row_bands, void *stream)
+{
+    if (!b || (!frames && n)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    if (b->persistent) return rd_batch_develop_multi(b, frames, n, (hipStream_t)stream);
+    const uint32_t units = b->h / 2u + 1u;
+    uint32_t bands = row_bands ? row_bands : 1u;
+    if (bands > units) bands = units;
+    hipStream_t lanes[2] = { (hipStream_t)stream, (hipStream_t)stream };
+    const bool fork = b->n_streams > 1 && (uint64_t)n * bands > 1u;
+    if (fork) {
+        RD_HIP(hipEventRecord(b->ev_fork, lanes[0]));
+        RD_HIP(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
+        lanes[1] = b->aux;
+    }
+    int rc = RD_OK;
+    size_t launch = 0;
+    b->last_launches = 0;
+    rd_scratch::lease ls[2] = { b->scratch.get(lanes[0], false), rd_scratch::lease{} };
+    if (fork) ls[1] = b->scratch.get(lanes[1], false);
+    if (ls[0].idx < 0 || (fork && ls[1].idx < 0)) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    for (size_t f = 0; f < n && rc == RD_OK; ++f) {
+        const rd_frame &fr = frames[f];
+        if (!fr.cfa_dev || !fr.out_dev) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f); break; }
+        if ((uintptr_t)fr.cfa_dev % 4u) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: cfa_dev not 4-byte aligned", f); break; }
+        if ((uintptr_t)fr.out_dev % rd_align_for(b->fmt)) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: out_dev misaligned", f); break; }
+        if (fr.matrix_layout != RD_MATRIX_REFERENCE && fr.matrix_layout != RD_MATRIX_ROW_MAJOR) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: unknown matrix layout %u", f, fr.matrix_layout); break; }
+        const rd_ku u = rd_frame_ku(fr.params, fr.wb_multipliers, fr.color_matrix, 1.0f, 0.0f, 0.0f, fr.black_level,
+                                    b->math_mode, fr.matrix_layout);
+        for (uint32_t k = 0; k < bands && rc == RD_OK; ++k, ++launch) {
+            const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
+            const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
+            const size_t lane = fork ? (launch & 1u) : 0u;
+            unsigned long long *slab = b->slab64 ? b->slab64 + lane * (size_t)b->blocks * 768u : nullptr;
+            rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0, u1,
+                                   b->hist, b->math_mode, nullptr, slab, b->blocks, ls[lane].tq, lanes[lane], nullptr);
+            if (rc == RD_OK) b->last_launches += 1;
+        }
+    }
+    b->scratch.used(ls[0], lanes[0], rc != RD_OK);
+    if (fork) b->scratch.used(ls[1], lanes[1], rc != RD_OK);
+    if (fork) {                                  // join even after an error: what was enqueued stays ordered
+        RD_HIP(hipEventRecord(b->ev_join, b->aux));
+        RD_HIP(hipStreamWaitEvent(lanes[0], b->ev_join, 0));
+    }
+    return rc;
+}
+
+extern "C" uint32_t rd_batch_last_launch_count(const rd_batch *b) { return b ? b->last_launches : 0u; }
+
+extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
+{
+    if (!b || !hist_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    hipLaunchKernelGGL(rd_reduce_slab64, dim3(24), dim3(RD_FOLD_THREADS), 0, (hipStream_t)stream, b->slab64,
+                       b->blocks * b->n_streams, (unsigned long long *)hist_dev);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_node_batch: the batch path over the GPUs of one node from ONE process (SURVEY.md section 8b "Batch", 8e)
+//
+// Frames share nothing (the demosaic clamps at the frame edge, shaders.rs:163-166), so frame i simply belongs to device
+// i mod N; its CFA plane and surface live in that device's HBM and no pixel crosses xGMI.  One rd_batch, one stream and
+// one 768 x u64 histogram per device; enqueueing is done by one host thread per device.  The only exchange is the global
+// histogram: ncclAllReduce(768, ncclUint64, ncclSum) over RCCL (librccl.so is loaded on first use and only when N > 1;
+// u64 because 2048 x 24 MP overflows u32).  With N = 1 there is no communicator.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct rd_rccl_api {
+    void *handle = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+    bool ok = false;
+    bool standin = false;                        // RD_NODE_REDUCE=standin: the tests' stand-in, not RCCL (ranks may share a device)
+};
+constexpr int RD_NCCL_UINT64 = 5, RD_NCCL_SUM = 0;           // rccl.h: ncclUint64, ncclSum
+
+rd_rccl_api &rd_rccl()
+{
+    static rd_rccl_api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = getenv("RAWDEV_RCCL_LIB");
+        const char *mode = getenv("RD_NODE_REDUCE");
+        const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        // One RCCL per process: a copy that is already mapped (a PyTorch process has its own) serves us too and wins over
+        // RAWDEV_RCCL_LIB, which only names the file to load when none is.  The exception is explicit:
+        // RD_NODE_REDUCE=standin (tests) loads exactly the file RAWDEV_RCCL_LIB names -- the host-memory stand-in of
+        // tests/cpp/rccl_standin.cpp -- and only then may ranks share a device.
+        if (mode && !strcmp(mode, "standin")) {
+            if (!env || !*env) { api.error = "RD_NODE_REDUCE=standin needs RAWDEV_RCCL_LIB=<the stand-in library>"; return; }
+            api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
+            api.standin = true;
+        }
+        for (const char *n : { "librccl.so.1", "librccl.so" })
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (!api.handle && env && *env) {
+            api.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { api.error = std::string("cannot load RAWDEV_RCCL_LIB=") + env + ": " + (dlerror() ? dlerror() : "?"); return; }
+        }
+        for (const char *n : names)
+            if (!api.handle && n && *n) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) { api.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(api.handle, n); if (!p && api.error.empty()) api.error = std::string("librccl.so lacks ") + n; return p; };
+        api.CommInitAll = (int (*)(void **, int, const int *))sym("ncclCommInitAll");
+        api.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+        api.GroupStart = (int (*)())sym("ncclGroupStart");
+        api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+        api.ok = api.error.empty();
+    });
+    return api;
+}
+}  // namespace
+
+enum { RD_NODE_REDUCE_NONE = 0, RD_NODE_REDUCE_RCCL = 1, RD_NODE_REDUCE_HOST = 2 };
+
+struct rd_node_batch {
+    uint32_t n = 0, w = 0, h = 0, fmt = 0;
+    bool hist = false;
+    int reduce = RD_NODE_REDUCE_NONE;
+    std::vector<int> devices;
+    std::vector<rd_batch *> batches;
+    std::vector<hipStream_t> streams;
+    std::vector<uint64_t *> hist_dev;          // 768 x u64 per device
+    std::vector<void *> comms;                 // ncclComm_t per device (RCCL only)
+    std::vector<std::vector<rd_frame>> share;  // the frames of the current call, per device
+};
+
+extern "C" uint32_t rd_node_batch_device_of(uint32_t n_devices, size_t frame_index)
+{
+    return n_devices ? (uint32_t)(frame_index % n_devices) : 0u;      // frame i -> GPU i mod N
+}
+
+extern "C" void rd_node_batch_destroy(rd_node_batch *nb)
+{
+    if (!nb) return;
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        if (d >= nb->streams.size() || !nb->streams[d]) continue;      // nothing was set up on this entry (failed create)
+        rd_devguard g(nb->devices[d]);
+        (void)hipStreamSynchronize(nb->streams[d]);
+    }
+    if (nb->reduce == RD_NODE_REDUCE_RCCL && rd_rccl().ok)
+        for (void *c : nb->comms) if (c) (void)rd_rccl().CommDestroy(c);
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        if (d < nb->batches.size()) rd_batch_destroy(nb->batches[d]);
+        const bool any = (d < nb->hist_dev.size() && nb->hist_dev[d]) || (d < nb->streams.size() && nb->streams[d]);
+        if (!any) continue;
+        rd_devguard g(nb->devices[d]);
+        if (nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
+        if (nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
+    }
+    delete nb;
+}
+
+extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
+                                    uint32_t with_histogram, rd_node_batch **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!devices || !n_devices || n_devices > 64) return rd_fail(RD_ERR_INVALID_ARG, "need 1..64 devices");
+    bool dup = false;
+    for (uint32_t a = 0; a < n_devices; ++a)
+        for (uint32_t b = a + 1; b < n_devices; ++b) dup = dup || devices[a] == devices[b];
+    const char *env = getenv("RD_NODE_REDUCE");              // "host": fold on the host; "rccl": a communicator even for N = 1;
+    const bool want_host = env && !strcmp(env, "host");      // "standin": the RCCL branch over the tests' stand-in library
+    const bool want_standin = env && !strcmp(env, "standin");
+    const bool want_rccl = want_standin || (env && !strcmp(env, "rccl"));
+    // A device listed twice is a rehearsal of N > 1 on a one-GPU box: allowed only on explicit request -- the host fold, or
+    // the stand-in for librccl (real RCCL wants one rank per device).
+    if (dup && !want_host && !want_standin)
+        return rd_fail(RD_ERR_INVALID_ARG, "device list holds a device twice (RCCL wants one rank per device; RD_NODE_REDUCE=host "
+                                           "allows it for rehearsals on a one-GPU box)");
+    rd_node_batch *nb = new (std::nothrow) rd_node_batch;
+    if (!nb) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    nb->n = n_devices; nb->w = width; nb->h = height; nb->fmt = format; nb->hist = with_histogram != 0;
+    nb->devices.assign(devices, devices + n_devices);
+    nb->batches.assign(n_devices, nullptr);
+    nb->streams.assign(n_devices, nullptr);
+    nb->hist_dev.assign(n_devices, nullptr);
+    nb->comms.assign(n_devices, nullptr);
+    nb->share.resize(n_devices);
+    int rc = RD_OK;
+    for (uint32_t d = 0; d < n_devices && rc == RD_OK; ++d) {
+        rc = rd_batch_create(devices[d], width, height, format, with_histogram, &nb->batches[d]);
+        if (rc) break;
+        rd_devguard g(devices[d]);
+        hipError_t e = hipStreamCreateWithFlags(&nb->streams[d], hipStreamNonBlocking);
+        if (e == hipSuccess && nb->hist) e = hipMalloc((void **)&nb->hist_dev[d], 768 * sizeof(uint64_t));
+        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "device %d: %s", devices[d], hipGetErrorString(e));
+    }
+    if (rc == RD_OK && nb->hist) {
+        if (want_host) nb->reduce = n_devices > 1 ? RD_NODE_REDUCE_HOST : RD_NODE_REDUCE_NONE;
+        else if (n_devices > 1 || want_rccl) {
+            rd_rccl_api &api = rd_rccl();
+            if (!api.ok) rc = rd_fail(RD_ERR_UNSUPPORTED, "global histogram over %u devices needs RCCL: %s", n_devices, api.error.c_str());
+            else {
+                const int r = api.CommInitAll(nb->comms.data(), (int)n_devices, nb->devices.data());
+                if (r != 0) rc = rd_fail(RD_ERR_HIP, "ncclCommInitAll: %s", api.GetErrorString(r));
+                else nb->reduce = RD_NODE_REDUCE_RCCL;
+            }
+        }
+    }
+    if (rc) { std::string keep = g_err; rd_node_batch_destroy(nb); snprintf(g_err, sizeof g_err, "%s", keep.c_str()); return rc; }
+    *out = nb;
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_set_math_mode(rd_node_batch *nb, uint32_t mode)
+{
+    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
+    for (rd_batch *b : nb->batches) { int rc = rd_batch_set_math_mode(b, mode); if (rc) return rc; }
+    return RD_OK;
+}
+
+// run fn(d) for every device, on one host thread per device when there is more than one; first error wins
+template <typename F> static int rd_node_for_each(rd_node_batch *nb, F fn)
+{
+    if (nb->n == 1) return fn(0u);
+    std::vector<int> rcs(nb->n, RD_OK);
+    std::vector<std::string> msgs(nb->n);
+    std::vector<std::thread> th;
+    th.reserve(nb->n);
+    for (uint32_t d = 0; d < nb->n; ++d)
+        th.emplace_back([&, d] { rcs[d] = fn(d); if (rcs[d]) msgs[d] = rd_last_error(); });
+    for (auto &t : th) t.join();
+    for (uint32_t d = 0; d < nb->n; ++d)
+        if (rcs[d]) return rd_fail(rcs[d], "device %d: %s", nb->devices[d], msgs[d].c_str());
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_frames, uint32_t row_bands)
+{
+    if (!nb || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    for (auto &v : nb->share) v.clear();
+    for (size_t i = 0; i < n_frames; ++i) nb->share[rd_node_batch_device_of(nb->n, i)].push_back(frames[i]);
+    return rd_node_for_each(nb, [&](uint32_t d) -> int {
+        const std::vector<rd_frame> &v = nb->share[d];
+        return v.empty() ? (int)RD_OK : rd_batch_develop(nb->batches[d], v.data(), v.size(), row_bands, nb->streams[d]);
+    });
+}
+
+extern "C" void *rd_node_batch_stream(rd_node_batch *nb, uint32_t index)
+{
+    return nb && index < nb->n ? (void *)nb->streams[index] : nullptr;
+}
+
+extern "C" uint32_t rd_node_batch_last_launch_count(const rd_node_batch *nb, uint32_t index)
+{
+    return nb && index < nb->n ? rd_batch_last_launch_count(nb->batches[index]) : 0u;
+}
+
+extern "C" int rd_node_batch_reduce_kind(const rd_node_batch *nb) { return nb ? nb->reduce : -1; }
+
+// test hook: what devices[index]'s 768 x u64 buffer holds after the last rd_node_batch_histogram (after an all-reduce
+// every device must hold the global sum, not only the one the call reads back)
+extern "C" int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768])
+{
+    if (!nb || !hist || index >= nb->n || !nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "rd_debug_node_histogram_of: bad argument");
+    rd_devguard g(nb->devices[index]);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[index]);
+    RD_HIP(hipMemcpyAsync(hist, nb->hist_dev[index], 768 * sizeof(uint64_t), hipMemcpyDeviceToHost, nb->streams[index]));
+    RD_HIP(hipStreamSynchronize(nb->streams[index]));
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_synchronize(rd_node_batch *nb)
+{
+    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        rd_devguard g(nb->devices[d]);
+        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
+        RD_HIP(hipStreamSynchronize(nb->streams[d]));
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768])
+{
+    if (!nb || !hist) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
+    // per-device fold of the slabs into 768 x u64, on each device's stream (after the launches enqueued there)
+    for (uint32_t d = 0; d < nb->n; ++d) {
+        int rc = rd_batch_histogram(nb->batches[d], nb->hist_dev[d], nb->streams[d]);
+        if (rc) return rc;
+    }
+    if (nb->reduce == RD_NODE_REDUCE_RCCL) {                  // one in-place all-reduce of 6 KiB per device, grouped
+        rd_rccl_api &api = rd_rccl();
+        int r = api.GroupStart();
+        for (uint32_t d = 0; d < nb->n && r == 0; ++d) {
+            rd_devguard g(nb->devices[d]);
+            r = api.AllReduce(nb->hist_dev[d], nb->hist_dev[d], 768, RD_NCCL_UINT64, RD_NCCL_SUM, nb->comms[d], nb->streams[d]);
+        }
+        const int r2 = api.GroupEnd();
+        if (r == 0) r = r2;
+        if (r != 0) return rd_fail(RD_ERR_HIP, "ncclAllReduce: %s", api.GetErrorString(r));
+    }
+    const uint32_t take = nb->reduce == RD_NODE_REDUCE_HOST ? nb->n : 1u;      // after an all-reduce every device holds the sum
+    uint64_t part[768];
+    memset(hist, 0, 768 * sizeof(uint64_t));
+    for (uint32_t d = 0; d < take; ++d) {
+        rd_devguard g(nb->devices[d]);
+        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
+        RD_HIP(hipMemcpyAsync(part, nb->hist_dev[d], sizeof part, hipMemcpyDeviceToHost, nb->streams[d]));
+        RD_HIP(hipStreamSynchronize(nb->streams[d]));
+        for (int k = 0; k < 768; ++k) hist[k] += part[k];
+    }
+    return rd_node_batch_synchronize(nb);                      // the call returns with every device's work done
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_exporter: develop -> HBM slot -> pinned host slot, copy stream overlapping the compute stream
+// ------------------------------------------------------------------------------------------------
+struct rd_export_slot {
+    void *dev = nullptr;
+    void *host = nullptr;
+    hipEvent_t kernel_done = nullptr, copy_done = nullptr;
+    bool busy = false, used = false;
+};
+
+struct rd_exporter {
+    int device = 0;
+    uint32_t w = 0, h = 0, fmt = 0, math_mode = RD_MATH_STRICT, n_slots = 0, next = 0;
+    size_t bytes = 0;
+    rd_launch_cfg cfg;
+    hipStream_t compute = nullptr, copy = nullptr;
+    rd_export_slot *slots = nullptr;
+    rd_scratch scratch;
+    std::mutex mu;
+};
+
+extern "C" void rd_exporter_destroy(rd_exporter *e)
+{
+    if (!e) return;
+    {
+        rd_devguard g(e->device);
+        if (e->compute) (void)hipStreamSynchronize(e->compute);
+        if (e->copy) (void)hipStreamSynchronize(e->copy);
+        for (uint32_t i = 0; e->slots && i < e->n_slots; ++i) {
+            if (e->slots[i].dev) (void)hipFree(e->slots[i].dev);
+            if (e->slots[i].host) (void)hipHostFree(e->slots[i].host);
+            if (e->slots[i].kernel_done) (void)hipEventDestroy(e->slots[i].kernel_done);
+            if (e->slots[i].copy_done) (void)hipEventDestroy(e->slots[i].copy_done);
+        }
+        if (e->compute) (void)hipStreamDestroy(e->compute);
+        if (e->copy) (void)hipStreamDestroy(e->copy);
+        e->scratch.release();
+    }
+    delete[] e->slots;
+    delete e;
+}
+
+extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t math_mode, uint32_t n_slots,
+                                  rd_exporter **out)
+{
+    if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!w || !h || !n_slots || n_slots > 64) return rd_fail(RD_ERR_INVALID_ARG, "bad frame size or slot count");
+    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "export needs an even frame width (got %u)", w);
+    const size_t bpp = rd_format_bytes_per_pixel(fmt);
+    if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
+    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 export needs width %% 128 == 0 (got %u)", w);
+    if (math_mode != RD_MATH_STRICT && math_mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", math_mode);
+    if (!(rd_identity_map(w) && rd_identity_map(h))) return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h);
+    int n_cu = 0;
+    int rc = rd_check_device(device, &n_cu);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_q8_lut_ensure(device);
+    if (rc) return rc;
+    rd_exporter *e = new (std::nothrow) rd_exporter;
+    if (!e) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    e->device = device; e->w = w; e->h = h; e->fmt = fmt; e->math_mode = math_mode; e->n_slots = n_slots;
+    e->bytes = (size_t)w * h * bpp;
+    e->cfg.n_cu = n_cu;
+    e->slots = new (std::nothrow) rd_export_slot[n_slots];
+    hipError_t err = e->slots ? hipSuccess : hipErrorOutOfMemory;
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
+    for (uint32_t i = 0; err == hipSuccess && i < n_slots; ++i) {
+        err = hipMalloc(&e->slots[i].dev, e->bytes);
+        if (err == hipSuccess) err = hipHostMalloc(&e->slots[i].host, e->bytes, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].kernel_done, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].copy_done, hipEventDisableTiming);
+    }
+    if (err != hipSuccess) {
+        int code = rd_fail(err == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "exporter setup failed: %s", hipGetErrorString(err));
+        rd_exporter_destroy(e);
+        return code;
+    }
+    *out = e;
+    return RD_OK;
+}
+
+extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out)
+{
+    if (!e || !fr || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!fr->cfa_dev || ((uintptr_t)fr->cfa_dev % 4u)) return rd_fail(RD_ERR_INVALID_ARG, "cfa_dev NULL or not 4-byte aligned");
+    rd_devguard g(e->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const uint32_t si = e->next;
+    rd_export_slot &s = e->slots[si];
+    if (s.busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u has not been released (ring of %u full)", si, e->n_slots);
+    // the previous copy out of this HBM slot must have finished before the kernel overwrites it
+    if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
+    if (fr->matrix_layout != RD_MATRIX_REFERENCE && fr->matrix_layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", fr->matrix_layout);
+    const rd_ku u = rd_frame_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode, fr->matrix_layout);
+    const rd_scratch::lease l = e->scratch.get(e->compute, false);
+    if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
+                               e->math_mode, nullptr, nullptr, 0, l.tq, e->compute, nullptr);
+    e->scratch.used(l, e->compute, rc != RD_OK);
+    if (rc) return rc;
+    RD_HIP(hipEventRecord(s.kernel_done, e->compute));
+    RD_HIP(hipStreamWaitEvent(e->copy, s.kernel_done, 0));
+    RD_HIP(hipMemcpyAsync(s.host, s.dev, e->bytes, hipMemcpyDeviceToHost, e->copy));
+    RD_HIP(hipEventRecord(s.copy_done, e->copy));
+    s.busy = true; s.used = true;
+    e->next = (si + 1u) % e->n_slots;
+    *slot_out = si;
+    return RD_OK;
+}
+
+extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len)
+{
+    if (!e || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
+    rd_devguard g(e->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->slots[slot].busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u holds no frame", slot);
+        ev = e->slots[slot].copy_done;
+    }
+    RD_HIP(hipEventSynchronize(ev));
+    *data = e->slots[slot].host;
+    if (len) *len = e->bytes;
+    return RD_OK;
+}
+
+extern "C" int rd_exporter_release(rd_exporter *e, uint32_t slot)
+{
+    if (!e) return rd_fail(RD_ERR_INVALID_ARG, "NULL exporter");
+    if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->slots[slot].busy = false;
+    return RD_OK;
+}
+

@@ -164,7 +164,7 @@ def test_product_never_reaches_into_the_oracle():
     for base in ("raweditor_amd", "include"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
             for f in files:
-                if not f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                if not f.endswith((".py", ".h", ".hpp", ".hip", ".inl", ".cpp", ".c")):
                     continue
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 for line in text.splitlines():
