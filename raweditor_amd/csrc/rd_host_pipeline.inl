@@ -518,53 +518,89 @@ static int rd_render_full_host(rd_pipeline *p, rd_lane *l, const rd_shot &sh, ui
     if (bands > units) bands = units;
     if (!bands) bands = 1u;
     size_t band_end[RD_BANDS_MAX];                           // bytes of the surface complete after band k
-    int rc = RD_OK;
-    for (uint32_t k = 0; k < bands && rc == RD_OK; ++k) {
-        const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands), u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
+    for (uint32_t k = 0; k < bands; ++k) {
+        const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
         const uint32_t row_hi = 2u * (u1 - 1u) < H ? 2u * (u1 - 1u) + 1u : H;      // exclusive: the last unit's row b
         band_end[k] = k + 1u == bands ? need : (size_t)row_hi * row_bytes;
-        rc = rd_pipeline_enqueue(p, sh, W, H, fmt, l->out_buf, hist ? l->hist_dev : nullptr, l->compute, u0, u1);
-        if (rc == RD_OK) RD_HIP(hipEventRecord(l->kev[k], l->compute));
     }
-    if (rc) return rc;
+    // The chunks of the read-back.  Page-locked destination: band-aligned pieces that grow (bands 0 | 1 | 2-3 | 4-7: the first
+    // bytes leave as soon as band 0 is done, the tail is two large transfers; RD_COPY_CHUNK_MB = fixed-size pieces instead).
+    // Pageable destination: RD_STAGE_BYTES pieces through the staging slots.
     const bool pinned = rd_is_pinned_host(dst, need);
-    static const size_t chunk_pinned = (size_t)rd_env_u32("RD_COPY_CHUNK_MB", 16) << 20;
-    const size_t chunk = pinned ? chunk_pinned : RD_STAGE_BYTES;
-    const size_t nchunks = (need + chunk - 1) / chunk;
+    static const size_t chunk_fixed = (size_t)rd_env_u32("RD_COPY_CHUNK_MB", 0) << 20;
+    struct piece { size_t off, len; };
+    piece grown[RD_BANDS_MAX];
+    size_t npieces = 0;
+    const bool growing = pinned && !chunk_fixed;
+    const size_t chunk = pinned ? chunk_fixed : RD_STAGE_BYTES;
+    if (growing) {
+        size_t off = 0;
+        for (uint32_t k = 0, group = 1, used = 0; k < bands; ++k) {
+            if (++used == group || k + 1u == bands) {
+                grown[npieces++] = piece{ off, band_end[k] - off };
+                off = band_end[k];
+                used = 0;
+                if (npieces >= 2) group *= 2u;
+            }
+        }
+    } else {
+        npieces = (need + chunk - 1) / chunk;
+    }
+    auto piece_of = [&](size_t c) -> piece {
+        if (growing) return grown[c];
+        return piece{ c * chunk, need - c * chunk < chunk ? need - c * chunk : chunk };
+    };
     uint32_t waited = 0;                                     // bands [0, waited) are already ordered before the copy stream's tail
-    auto enqueue_chunk = [&](size_t c, void *to) -> hipError_t {
-        const size_t off = c * chunk, len = need - off < chunk ? need - off : chunk;
+    auto enqueue_piece = [&](size_t c, void *to) -> hipError_t {
         hipError_t e = hipSuccess;
-        while (e == hipSuccess && waited < bands && (waited == 0 || band_end[waited - 1u] < off + len))
+        const piece pc = piece_of(c);
+        while (e == hipSuccess && waited < bands && (waited == 0 || band_end[waited - 1u] < pc.off + pc.len))
             e = hipStreamWaitEvent(l->copy, l->kev[waited++], 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(to, (const char *)l->out_buf + off, len, hipMemcpyDeviceToHost, l->copy);
+        if (e == hipSuccess) e = hipMemcpyAsync(to, (const char *)l->out_buf + pc.off, pc.len, hipMemcpyDeviceToHost, l->copy);
         return e;
     };
+    const bool staged = !pinned;
+    bool stage_ok = true;
+    if (staged) {
+        for (int j = 0; j < RD_STAGE_SLOTS; ++j)
+            if (!l->stage[j] && hipHostMalloc(&l->stage[j], RD_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) stage_ok = false;
+        if (!stage_ok) return rd_fail(RD_ERR_OOM, "pinned staging allocation failed");
+    }
+    // Launch the bands; a piece is enqueued the moment the last band it needs has been (the host spends ~10 us per launch:
+    // waiting for all eight before the first copy is even enqueued would cost the transfer that long).
+    size_t next = 0;                                         // next piece to enqueue
     hipError_t e = hipSuccess;
+    int rc = RD_OK;
+    for (uint32_t k = 0; k < bands && rc == RD_OK && e == hipSuccess; ++k) {
+        const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands), u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
+        rc = rd_pipeline_enqueue(p, sh, W, H, fmt, l->out_buf, hist ? l->hist_dev : nullptr, l->compute, u0, u1);
+        if (rc == RD_OK) e = hipEventRecord(l->kev[k], l->compute);
+        while (rc == RD_OK && e == hipSuccess && next < npieces && (pinned || next < RD_STAGE_SLOTS) &&
+               piece_of(next).off + piece_of(next).len <= band_end[k]) {
+            e = enqueue_piece(next, pinned ? (void *)(dst + piece_of(next).off) : l->stage[next % RD_STAGE_SLOTS]);
+            if (e == hipSuccess && staged) e = hipEventRecord(l->cev[next % RD_STAGE_SLOTS], l->copy);
+            ++next;
+        }
+    }
+    if (rc) { (void)hipStreamSynchronize(l->copy); (void)hipStreamSynchronize(l->compute); return rc; }
     if (pinned) {
-        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) e = enqueue_chunk(c, dst + c * chunk);
         if (e == hipSuccess && hist) {
             e = hipStreamWaitEvent(l->copy, l->kev[0], 0);
             if (e == hipSuccess) e = hipMemcpyAsync(hist, l->hist_dev, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, l->copy);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(l->copy);
     } else {
-        for (int j = 0; j < RD_STAGE_SLOTS && e == hipSuccess; ++j)
-            if (!l->stage[j]) e = hipHostMalloc(&l->stage[j], RD_STAGE_BYTES, hipHostMallocDefault);
-        for (size_t c = 0; c < nchunks && c < RD_STAGE_SLOTS && e == hipSuccess; ++c) {
-            e = enqueue_chunk(c, l->stage[c]);
-            if (e == hipSuccess) e = hipEventRecord(l->cev[c], l->copy);
-        }
         rd_copy_pool &pool = rd_copy_pool::get();
         rd_advise_destination(dst, need);
-        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
-            const size_t j = c % RD_STAGE_SLOTS, off = c * chunk, len = need - off < chunk ? need - off : chunk;
+        for (size_t c = 0; c < npieces && e == hipSuccess; ++c) {
+            const size_t j = c % RD_STAGE_SLOTS;
             e = hipEventSynchronize(l->cev[j]);
             if (e != hipSuccess) break;
-            pool.copy(dst + off, l->stage[j], len);
-            if (c + RD_STAGE_SLOTS < nchunks) {              // the slot is free again: the chunk three ahead goes into it
-                e = enqueue_chunk(c + RD_STAGE_SLOTS, l->stage[j]);
-                if (e == hipSuccess) e = hipEventRecord(l->cev[j], l->copy);
+            pool.copy(dst + piece_of(c).off, l->stage[j], piece_of(c).len);
+            if (next < npieces) {                            // the slot is free again: the next piece goes into it (next == c + slots)
+                e = enqueue_piece(next, l->stage[next % RD_STAGE_SLOTS]);
+                if (e == hipSuccess) e = hipEventRecord(l->cev[next % RD_STAGE_SLOTS], l->copy);
+                ++next;
             }
         }
         if (e == hipSuccess && hist) {
