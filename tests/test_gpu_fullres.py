@@ -314,3 +314,52 @@ def test_pipeline_per_image_does_not_leak(gpu_lib, refc):
     after = free_mb()
     assert before - after < 64, f"device memory shrank by {before - after:.0f} MiB over 40 pipelines"
     pin.free()
+
+
+KNOB_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import raweditor_amd as ra
+from oracle import ref_c as refc
+from tests.gpu_util import DevBuf
+from tests.helpers import CM_TEST, WB_DAYLIGHT, random_cfa, random_params
+h, w = 2056, 2048
+rng = np.random.default_rng([0x52415745, 95])
+cfa = random_cfa(rng, h, w)
+params = random_params(rng)
+u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST)
+f32 = refc.render_f32(cfa, u, nthreads=8)
+exp = refc.pack_u8(f32)
+pipe = ra.RenderPipeline.new(1, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+pin = ra.PinnedBytes(h * w * 4)
+assert np.array_equal(pipe.render_full_res_to_bytes().reshape(h, w, 4), exp)
+assert np.array_equal(pipe.render_full_res_to_bytes(out=pin.array).reshape(h, w, 4), exp)
+got, hist = pipe.render(fmt=ra.FMT_RGBA_F32, with_histogram=True)
+assert np.array_equal(got.view(np.uint32), f32.view(np.uint32)) and np.array_equal(hist, refc.histogram(exp))
+out, hd = DevBuf(h * w * 16), DevBuf(768 * 4)
+for _ in range(3):                                            # rd_render_device: develop + fold (RD_GRAPH=1: as one graph, re-parameterised)
+    pipe.render_device(w, h, ra.FMT_RGBA_F32, out.ptr, hd.ptr)
+    pipe.update_uniforms(ra.EditParams(**params))
+from tests.gpu_util import sync
+sync()
+assert np.array_equal(out.to_array(np.float32, (h, w, 4)).view(np.uint32), f32.view(np.uint32))
+assert np.array_equal(hd.to_array(np.uint32, (768,)).reshape(3, 256), refc.histogram(exp))
+print("knobs ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"RD_COPY_THREADS": "0"}, {"RD_COPY_THREADS": "9"}, {"RD_ASSUME_PAGEABLE": "1"}, {"RD_RENDER_BANDS": "1"},
+                                 {"RD_RENDER_BANDS": "3", "RD_COPY_CHUNK_MB": "4"}, {"RD_DST_ADVISE": "huge"}, {"RD_DST_ADVISE": "populate"},
+                                 {"RD_GRAPH": "1"}], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_readback_knobs_do_not_change_bytes(gpu_lib, env):
+    """The host-side switches of the read-back (helper threads, forced staging, band count, fixed piece size, madvise hints)
+    and the graph form of develop + fold are read once per process: each runs in a fresh interpreter and must give the
+    oracle's bytes for a pageable and a page-locked destination, a fused-histogram render and rd_render_device."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", KNOB_SCRIPT % {"root": root}], env=dict(os.environ, **env), capture_output=True,
+                         text=True, timeout=300, cwd=root)
+    assert out.returncode == 0 and "knobs ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
