@@ -889,6 +889,10 @@ def run_ranks(args):
         diag, err2 = summarize_ranks(records, world, world_seen, rule_backend)
         result.update(diag)
         result["backend"] = backend if world > 1 else None
+        try:
+            result["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 else None
+        except Exception:  # noqa: BLE001
+            result["rccl_version"] = None
         diag_err = diag_err or err2
         if diag_err:
             result["invalid"] = diag_err

@@ -103,7 +103,6 @@ struct rd_lane {
     void *stage[RD_STAGE_SLOTS] = {};
     hipEvent_t kev[RD_BANDS_MAX] = {};           // band k's kernel has finished (compute stream)
     hipEvent_t cev[RD_STAGE_SLOTS] = {};         // the copy into staging slot j has finished (copy stream)
-    hipEvent_t done = nullptr;                   // the copy stream has drained this call's chunks
     bool busy = false;
 };
 
@@ -156,7 +155,6 @@ static void rd_lane_free(rd_lane *l)             // device set, nothing of the l
     for (void *s : l->stage) if (s) (void)hipHostFree(s);
     for (hipEvent_t e : l->kev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : l->cev) if (e) (void)hipEventDestroy(e);
-    if (l->done) (void)hipEventDestroy(l->done);
     delete l;
 }
 
@@ -170,7 +168,6 @@ static int rd_lane_new(rd_lane **out)            // device set
     if (e == hipSuccess) e = hipMalloc((void **)&l->hist_dev, 768 * sizeof(uint32_t));
     for (int k = 0; k < RD_BANDS_MAX && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&l->kev[k], hipEventDisableTiming);
     for (int k = 0; k < RD_STAGE_SLOTS && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&l->cev[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->done, hipEventDisableTiming);
     if (e != hipSuccess) {
         rd_lane_free(l);
         return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "render lane setup failed: %s", hipGetErrorString(e));
