@@ -708,23 +708,23 @@ def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
     H, W = cfas[0].shape
     out = {}
     for name, fmt, fname in (("rgb8", ra.FMT_RGB_U8, "rgb8"), ("rgba8", ra.FMT_RGBA_U8, "u8")):
-        ex = ra.Exporter(dev_index, W, H, fmt, n_slots=3)
+        ex = ra.Exporter(dev_index, W, H, fmt, n_slots=2)          # two slots: the copy of frame i under the kernel of frame i+1, nothing queued deeper (deeper rings measured slower)
         frames = [ex.frame(cfas[i % len(cfas)].data_ptr(), params[i % len(cfas)], WB, CM) for i in range(n_frames)]
         for _ in ex.export(frames[:6]):
             pass
         keep = None
         t0 = time.perf_counter()
-        n = 0
+        n, dt = 0, None
         for i, surf in ex.export(frames):
             n += 1
             if i == n_frames - 1:
-                keep = np.array(surf, copy=True)
-        dt = time.perf_counter() - t0
+                dt = time.perf_counter() - t0                # the last surface is in host memory: the clock stops here,
+                keep = np.array(surf, copy=True)             # the copy for the oracle check is not part of the ring's work
         i_last = (n_frames - 1) % len(cfas)
         ok, info = check_bands(fname, W, H, cfas[i_last], params[i_last], torch.from_numpy(keep.reshape(-1)), "strict", f"export ring {name}")
         nbytes = W * H * ra.BYTES_PER_PIXEL[fmt]
         out[name] = {"ms_per_frame": round(dt / n * 1e3, 3), "frames_per_s": round(n / dt, 1), "MP_per_s": round(n * W * H / dt / 1e6, 1),
-                     "GBps_over_pcie": round(n * nbytes / dt / 1e9, 1), "frames": n, "slots": 3,
+                     "GBps_over_pcie": round(n * nbytes / dt / 1e9, 1), "frames": n, "slots": 2,
                      "verified": bool(ok), "verified_note": f"{info} row bands of the last frame bit-identical to the oracle" if ok else str(info)}
         ex.close()
     out["config"] = (f"export ring (rd_exporter_*): {n_frames} x {W}x{H} frames resident in HBM -> fused develop -> pinned host ring, "

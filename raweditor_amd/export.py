@@ -21,7 +21,7 @@ from .edit import EditParams
 
 
 class Exporter:
-    def __init__(self, device: int, width: int, height: int, fmt: int = FMT_RGBA_U8, n_slots: int = 3,
+    def __init__(self, device: int, width: int, height: int, fmt: int = FMT_RGBA_U8, n_slots: int = 2,
                  math_mode: int = MATH_STRICT):
         self._h = C.c_void_p()
         self.width, self.height, self.fmt, self.n_slots = int(width), int(height), int(fmt), int(n_slots)

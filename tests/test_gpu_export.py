@@ -24,7 +24,7 @@ def test_exporter_ring(gpu_lib, refc, fmt_name):
     cfas = [random_cfa(rng, h, w) for _ in range(n)]
     ps = [random_params(rng) for _ in range(n)]
     dev = [DevBuf.from_array(c) for c in cfas]
-    ex = ra.Exporter(0, w, h, fmt, n_slots=3)
+    ex = ra.Exporter(0, w, h, fmt, n_slots=3)   # (three slots here on purpose: the default is two)
     frames = [ex.frame(d.ptr, ra.EditParams(**p), WB_DAYLIGHT, CM_TEST) for d, p in zip(dev, ps)]
     seen = []
     for i, surf in ex.export(frames):
