@@ -725,8 +725,39 @@ def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
                      "GBps_over_pcie": round(n * nbytes / dt / 1e9, 1), "frames": n, "slots": 2,
                      "verified": bool(ok), "verified_note": f"{info} row bands of the last frame bit-identical to the oracle" if ok else str(info)}
         ex.close()
+    # The same ring fed from HOST memory (rd_exporter_submit_host: the decoded files of a folder export, raw/loader.rs:11-19):
+    # upload of frame i+1, kernel of frame i+1 and read-back of frame i overlap; page-locked planes and pageable ones.
+    try:
+        ex = ra.Exporter(dev_index, W, H, ra.FMT_RGB_U8, n_slots=2)
+        k = min(4, len(cfas))
+        host = [np.ascontiguousarray(cfas[i].cpu().numpy()).view(np.uint16) for i in range(k)]
+        pins = [ra.PinnedBytes(W * H * 2) for _ in range(k)]
+        for pin, a in zip(pins, host):
+            pin.array.view(np.uint16)[:] = a.reshape(-1)
+        for name, planes in (("rgb8_from_pinned_host", [pin.array.view(np.uint16) for pin in pins]), ("rgb8_from_pageable_host", host)):
+            feed = [(planes[i % k], ex.frame(0, params[i % k], WB, CM)) for i in range(n_frames)]
+            for _ in ex.export_host(feed[:6]):
+                pass
+            keep, dt, n = None, None, 0
+            t0 = time.perf_counter()
+            for i, surf in ex.export_host(feed):
+                n += 1
+                if i == n_frames - 1:
+                    dt = time.perf_counter() - t0
+                    keep = np.array(surf, copy=True)
+            i_last = (n_frames - 1) % k
+            ok, info = check_bands("rgb8", W, H, cfas[i_last], params[i_last], torch.from_numpy(keep.reshape(-1)), "strict", f"export ring {name}")
+            out[name] = {"ms_per_frame": round(dt / n * 1e3, 3), "frames_per_s": round(n / dt, 1),
+                         "GBps_up_plus_down": round(n * (W * H * 2 + W * H * 3) / dt / 1e9, 1), "frames": n, "slots": 2,
+                         "verified": bool(ok), "verified_note": f"{info} row bands of the last frame bit-identical to the oracle" if ok else str(info)}
+        ex.close()
+        for pin in pins:
+            pin.free()
+    except Exception as exc:                                      # an extra must not cost the line
+        out["rgb8_from_host_error"] = f"{type(exc).__name__}: {exc}"
     out["config"] = (f"export ring (rd_exporter_*): {n_frames} x {W}x{H} frames resident in HBM -> fused develop -> pinned host ring, "
-                     "PCIe-inclusive; RGB8 = JPEG feed (alpha strip fused), RGBA8 = PNG feed")
+                     "PCIe-inclusive; RGB8 = JPEG feed (alpha strip fused), RGBA8 = PNG feed; *_from_*_host: the CFA planes "
+                     "start in host memory too (48 MB up + 72 MB down per frame)")
     return out
 
 def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None):

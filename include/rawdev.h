@@ -282,6 +282,13 @@ void rd_exporter_destroy(rd_exporter *e);
 /* Enqueue one frame (frame->out_dev is ignored; zoom 1 / pan 0).  *slot receives the ring slot used.  Fails with
  * RD_ERR_INVALID_ARG if that slot still holds an un-released frame. */
 int rd_exporter_submit(rd_exporter *e, const rd_frame *frame, uint32_t *slot);
+/* The same for a frame whose CFA plane is still in HOST memory -- RawDataResult.data as raw/loader.rs:11-19 hands it over
+ * (width*height u16, row-major; frame->cfa_dev is ignored): the plane is uploaded into the slot's own HBM copy on a third
+ * stream, so with a ring of two or more the upload of frame i+1, the kernel of frame i+1 and the read-back of frame i
+ * overlap (pipeline.rs:190-206's queue.write_texture + :526-606 for a stream of files).  A page-locked plane
+ * (rd_host_alloc) is read by the DMA engine where it lies and must stay untouched until rd_exporter_wait(slot) returns;
+ * any other memory is copied through page-locked staging before the call returns and may be reused at once. */
+int rd_exporter_submit_host(rd_exporter *e, const rd_frame *frame, const uint16_t *cfa_host, uint32_t *slot);
 /* Block until the slot's surface is in host memory.  *data (pinned, width*height*bpp bytes, tightly packed) stays
  * valid until rd_exporter_release(slot). */
 int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len);

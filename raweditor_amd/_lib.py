@@ -94,6 +94,7 @@ PROTOTYPES = {
     "rd_exporter_create": (_I, [_I, _U32, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),
     "rd_exporter_destroy": (None, [_VP]),
     "rd_exporter_submit": (_I, [_VP, C.POINTER(RdFrame), C.POINTER(_U32)]),
+    "rd_exporter_submit_host": (_I, [_VP, C.POINTER(RdFrame), _VP, C.POINTER(_U32)]),
     "rd_exporter_wait": (_I, [_VP, _U32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rd_exporter_release": (_I, [_VP, _U32]),
     "rd_selftest_q8": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),

@@ -587,6 +587,10 @@ struct rd_export_slot {
     void *host = nullptr;
     hipEvent_t kernel_done = nullptr, copy_done = nullptr;
     bool busy = false, used = false;
+    // rd_exporter_submit_host only (allocated by the first such call): the slot's own CFA plane in HBM and, for a pageable
+    // source, the page-locked staging it is copied through
+    void *cfa_dev = nullptr, *cfa_pin = nullptr;
+    hipEvent_t upload_done = nullptr;
 };
 
 struct rd_exporter {
@@ -594,7 +598,7 @@ struct rd_exporter {
     uint32_t w = 0, h = 0, fmt = 0, math_mode = RD_MATH_STRICT, n_slots = 0, next = 0;
     size_t bytes = 0;
     rd_launch_cfg cfg;
-    hipStream_t compute = nullptr, copy = nullptr;
+    hipStream_t compute = nullptr, copy = nullptr, upload = nullptr;
     rd_export_slot *slots = nullptr;
     rd_scratch scratch;
     std::mutex mu;
@@ -607,7 +611,11 @@ extern "C" void rd_exporter_destroy(rd_exporter *e)
         rd_devguard g(e->device);
         if (e->compute) (void)hipStreamSynchronize(e->compute);
         if (e->copy) (void)hipStreamSynchronize(e->copy);
+        if (e->upload) (void)hipStreamSynchronize(e->upload);
         for (uint32_t i = 0; e->slots && i < e->n_slots; ++i) {
+            if (e->slots[i].cfa_dev) (void)hipFree(e->slots[i].cfa_dev);
+            if (e->slots[i].cfa_pin) (void)hipHostFree(e->slots[i].cfa_pin);
+            if (e->slots[i].upload_done) (void)hipEventDestroy(e->slots[i].upload_done);
             if (e->slots[i].dev) (void)hipFree(e->slots[i].dev);
             if (e->slots[i].host) (void)hipHostFree(e->slots[i].host);
             if (e->slots[i].kernel_done) (void)hipEventDestroy(e->slots[i].kernel_done);
@@ -615,6 +623,7 @@ extern "C" void rd_exporter_destroy(rd_exporter *e)
         }
         if (e->compute) (void)hipStreamDestroy(e->compute);
         if (e->copy) (void)hipStreamDestroy(e->copy);
+        if (e->upload) (void)hipStreamDestroy(e->upload);
         e->scratch.release();
     }
     delete[] e->slots;
@@ -664,23 +673,52 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
     return RD_OK;
 }
 
-extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out)
+// cfa_host != nullptr: the frame's CFA plane comes from HOST memory (rd_exporter_submit_host) and travels through the slot's
+// own HBM plane on a third stream, so the upload of frame i+1 runs under the kernel and the read-back of frame i (PCIe is
+// full duplex).  A page-locked source is read by the DMA engine where it lies; a pageable one (RawDataResult's Vec<u16>) is
+// copied through page-locked staging in 8 MiB pieces -- helper threads copy piece k+1 while piece k is on the bus -- and is
+// free to be reused when the call returns.
+static int rd_exporter_submit_impl(rd_exporter *e, const rd_frame *fr, const uint16_t *cfa_host, uint32_t *slot_out)
 {
-    if (!e || !fr || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (!fr->cfa_dev || ((uintptr_t)fr->cfa_dev % 4u)) return rd_fail(RD_ERR_INVALID_ARG, "cfa_dev NULL or not 4-byte aligned");
     rd_devguard g(e->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", e->device);
     std::lock_guard<std::mutex> lk(e->mu);
     const uint32_t si = e->next;
     rd_export_slot &s = e->slots[si];
     if (s.busy) return rd_fail(RD_ERR_INVALID_ARG, "slot %u has not been released (ring of %u full)", si, e->n_slots);
+    if (fr->matrix_layout != RD_MATRIX_REFERENCE && fr->matrix_layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", fr->matrix_layout);
+    const uint16_t *cfa_dev = fr->cfa_dev;
+    if (cfa_host) {
+        const size_t cfa_bytes = (size_t)e->w * e->h * sizeof(uint16_t);
+        if (!e->upload) RD_HIP(hipStreamCreateWithFlags(&e->upload, hipStreamNonBlocking));
+        if (!s.cfa_dev) RD_HIP(hipMalloc(&s.cfa_dev, cfa_bytes));
+        if (!s.upload_done) RD_HIP(hipEventCreateWithFlags(&s.upload_done, hipEventDisableTiming));
+        // the slot's previous kernel read this plane: it has finished (its frame was waited for and released), but say so
+        if (s.used) RD_HIP(hipStreamWaitEvent(e->upload, s.kernel_done, 0));
+        const int kind = rd_host_memory_kind(cfa_host, cfa_bytes);
+        if (kind == RD_MEM_DEVICE) return rd_fail(RD_ERR_INVALID_ARG, "cfa_host is a device pointer: use rd_exporter_submit");
+        if (kind == RD_MEM_PINNED && !getenv("RD_ASSUME_PAGEABLE")) {
+            RD_HIP(hipMemcpyAsync(s.cfa_dev, cfa_host, cfa_bytes, hipMemcpyHostToDevice, e->upload));
+        } else {
+            if (!s.cfa_pin) RD_HIP(hipHostMalloc(&s.cfa_pin, cfa_bytes, hipHostMallocDefault));
+            else RD_HIP(hipEventSynchronize(s.upload_done));     // the staging's previous upload (long finished)
+            const size_t piece = (size_t)8 << 20;
+            for (size_t off = 0; off < cfa_bytes; off += piece) {
+                const size_t n = cfa_bytes - off < piece ? cfa_bytes - off : piece;
+                rd_copy_pool::get().copy((char *)s.cfa_pin + off, (const char *)cfa_host + off, n);
+                RD_HIP(hipMemcpyAsync((char *)s.cfa_dev + off, (const char *)s.cfa_pin + off, n, hipMemcpyHostToDevice, e->upload));
+            }
+        }
+        RD_HIP(hipEventRecord(s.upload_done, e->upload));
+        RD_HIP(hipStreamWaitEvent(e->compute, s.upload_done, 0));
+        cfa_dev = (const uint16_t *)s.cfa_dev;
+    }
     // the previous copy out of this HBM slot must have finished before the kernel overwrites it
     if (s.used) RD_HIP(hipStreamWaitEvent(e->compute, s.copy_done, 0));
-    if (fr->matrix_layout != RD_MATRIX_REFERENCE && fr->matrix_layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", fr->matrix_layout);
     const rd_ku u = rd_frame_ku(fr->params, fr->wb_multipliers, fr->color_matrix, 1.0f, 0.0f, 0.0f, fr->black_level, e->math_mode, fr->matrix_layout);
     const rd_scratch::lease l = e->scratch.get(e->compute, false);
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-    int rc = rd_enqueue_render(e->cfg, fr->cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
+    int rc = rd_enqueue_render(e->cfg, cfa_dev, e->w, e->h, e->w, e->h, e->fmt, s.dev, u, true, 0, e->h / 2u + 1u, false,
                                e->math_mode, nullptr, nullptr, 0, l.tq, e->compute, nullptr);
     e->scratch.used(l, e->compute, rc != RD_OK);
     if (rc) return rc;
@@ -692,6 +730,19 @@ extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *
     e->next = (si + 1u) % e->n_slots;
     *slot_out = si;
     return RD_OK;
+}
+
+extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out)
+{
+    if (!e || !fr || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!fr->cfa_dev || ((uintptr_t)fr->cfa_dev % 4u)) return rd_fail(RD_ERR_INVALID_ARG, "cfa_dev NULL or not 4-byte aligned");
+    return rd_exporter_submit_impl(e, fr, nullptr, slot_out);
+}
+
+extern "C" int rd_exporter_submit_host(rd_exporter *e, const rd_frame *fr, const uint16_t *cfa_host, uint32_t *slot_out)
+{
+    if (!e || !fr || !cfa_host || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    return rd_exporter_submit_impl(e, fr, cfa_host, slot_out);
 }
 
 extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len)

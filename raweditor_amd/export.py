@@ -45,6 +45,17 @@ class Exporter:
         check(_lib.lib().rd_exporter_submit(self._h, C.byref(frame), C.byref(slot)))
         return slot.value
 
+    def submit_host(self, cfa, frame: RdFrame) -> int:
+        """The frame's CFA plane from HOST memory (rd_exporter_submit_host): `cfa` is a contiguous uint16 array of
+        width*height samples -- a PinnedBytes view is read by the DMA engine in place (keep it untouched until wait()),
+        anything else is staged and free again when this returns.  frame.cfa_dev is ignored."""
+        a = np.ascontiguousarray(cfa, dtype=np.uint16).reshape(-1)
+        if a.size != self.width * self.height:
+            raise _lib.RawdevError(-1, f"cfa has {a.size} samples, expected {self.width}x{self.height}")
+        slot = C.c_uint32()
+        check(_lib.lib().rd_exporter_submit_host(self._h, C.byref(frame), a.ctypes.data_as(C.c_void_p), C.byref(slot)))
+        return slot.value
+
     def wait(self, slot: int) -> np.ndarray:
         """(h, w, c) view of the slot's pinned host buffer; valid until release(slot)."""
         data, n = C.c_void_p(), C.c_size_t()
@@ -65,6 +76,19 @@ class Exporter:
                 yield j, self.wait(s)
                 self.release(s)
             pending.append((i, self.submit(fr)))
+        for j, s in pending:
+            yield j, self.wait(s)
+            self.release(s)
+
+    def export_host(self, frames: Iterable[Tuple[np.ndarray, RdFrame]]) -> Iterator[Tuple[int, np.ndarray]]:
+        """export() for (cfa plane in host memory, frame) pairs: upload, develop and read-back of neighbouring frames overlap."""
+        pending = []
+        for i, (cfa, fr) in enumerate(frames):
+            if len(pending) == self.n_slots:
+                j, s = pending.pop(0)
+                yield j, self.wait(s)
+                self.release(s)
+            pending.append((i, self.submit_host(cfa, fr)))
         for j, s in pending:
             yield j, self.wait(s)
             self.release(s)

@@ -44,6 +44,59 @@ def test_exporter_ring(gpu_lib, refc, fmt_name):
     ex.close()
 
 
+@pytest.mark.parametrize("h,w,fmt_name", [(70, 256, "RGBA8"), (41, 130, "RGBA8"), (2056, 4224, "RGB8")])
+def test_exporter_from_host_planes(gpu_lib, refc, h, w, fmt_name):
+    """rd_exporter_submit_host: the CFA plane arrives in host memory (RawDataResult.data, raw/loader.rs:11-19) -- pageable
+    (staged, reusable at once: the source is scribbled over right after the call), page-locked (read in place), mixed with
+    device-resident frames in one ring; 17 MB planes cross the 8 MiB staging pieces."""
+    ra = gpu_lib
+    fmt = ra.FMT_RGB_U8 if fmt_name == "RGB8" else ra.FMT_RGBA_U8
+    n = 7 if h < 1000 else 5
+    rng = np.random.default_rng([6, h, w])
+    cfas = [random_cfa(rng, h, w, 65536 if k == 2 else 4096) for k in range(n)]
+    ps = [random_params(rng) for _ in range(n)]
+    exp = [refc.pack_u8(refc.render_f32(c, refc.make_uniforms(p, WB_DAYLIGHT, CM_TEST), nthreads=8)) for c, p in zip(cfas, ps)]
+    exp = [e[..., :3] if fmt_name == "RGB8" else e for e in exp]
+    ex = ra.Exporter(0, w, h, fmt, n_slots=2)
+    pins = [ra.PinnedBytes(h * w * 2) for _ in range(2)]
+    dev = DevBuf.from_array(cfas[3])
+    pending, seen = [], []
+
+    def drain_one():
+        j, s = pending.pop(0)
+        assert np.array_equal(ex.wait(s), exp[j]), (j, "host" if j != 3 else "device")
+        ex.release(s)
+        seen.append(j)
+
+    for k in range(n):
+        if len(pending) == 2:
+            drain_one()
+        fr = ex.frame(0, ra.EditParams(**ps[k]), WB_DAYLIGHT, CM_TEST)
+        if k == 3:                                           # a device-resident frame between host-fed ones
+            pending.append((k, ex.submit(ex.frame(dev.ptr, ra.EditParams(**ps[k]), WB_DAYLIGHT, CM_TEST))))
+        elif k % 2:                                          # page-locked source: DMA reads it in place
+            pin = pins[(k // 2) % 2]
+            pin.array.view(np.uint16)[:] = cfas[k].reshape(-1)
+            assert ra._lib.lib().rd_debug_is_pinned_host(pin.ptr, pin.nbytes) == 1
+            pending.append((k, ex.submit_host(pin.array.view(np.uint16), fr)))
+        else:                                                # pageable source: free for reuse when the call returns
+            src = cfas[k].copy()
+            pending.append((k, ex.submit_host(src, fr)))
+            src[:] = 0xdead
+    while pending:
+        drain_one()
+    assert seen == list(range(n))
+    got = [surf.copy() for _, surf in ex.export_host((c, ex.frame(0, ra.EditParams(**p), WB_DAYLIGHT, CM_TEST)) for c, p in zip(cfas, ps))]
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    with pytest.raises(ra.RawdevError):
+        ex.submit_host(cfas[0][:-1], ex.frame(0, ra.EditParams(), WB_DAYLIGHT, CM_TEST))       # wrong size
+    rc = ra._lib.lib().rd_exporter_submit_host(ex._h, None, None, None)
+    assert rc != 0
+    for pin in pins:
+        pin.free()
+    ex.close()
+
+
 def test_rgb8_surface_through_the_pipeline(gpu_lib, refc):
     """RD_FMT_RGB_U8 via rd_render: export kernel (W % 128 == 0), map kernel (other widths, preview), edges."""
     ra = gpu_lib
