@@ -356,6 +356,20 @@ def test_q8_pack_by_fma_is_the_pinned_pack_for_every_float_in_0_1(tmp_path):
     assert out.startswith("mismatches 0 "), out
 
 
+def test_copy_pool_under_thread_sanitizer(tmp_path):
+    """The host-side copy pool behind pageable render destinations and host-fed exports (raweditor_amd/csrc/rd_copy_pool.h:
+    plain C++, no HIP) built with -fsanitize=thread: four threads call copy() at once, sizes on both sides of the 4 MiB
+    serial threshold, unaligned on both sides; every copy exact, nothing written outside the range, no race reported
+    (a report makes the sanitizer exit with 66)."""
+    import subprocess
+    exe = tmp_path / "test_copy_pool"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread",
+                    os.path.join(ROOT, "tests", "cpp", "test_copy_pool.cpp"), "-o", str(exe)], check=True)
+    env = dict(os.environ, RD_COPY_THREADS="3", TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "copy pool ok" in r.stdout and "helpers 3" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
 def test_q8_threshold_table_construction_against_the_oracle(refc):
     """rd_q8_lut_table (no device): the export kernel's threshold table for the 8-bit code (rd_kernels.h, round 4), built on
     the host from the pinned gamma.  Evaluated here in plain integer arithmetic the way the kernel does --
