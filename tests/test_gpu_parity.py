@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): f32 surface within 1 ULP per channel; integer / 
 (CFA indexing, RGBA8 pack, f16 pack, histogram) bit-exact.  Because both sides implement the same
 pinned operation order we additionally assert that the f32 surface is bit-identical.
 """
+import ctypes as C
 import os
 import threading
 
@@ -470,6 +471,57 @@ def test_full_size_100mp_f16_row_bands(gpu_lib, refc):
     assert np.array_equal(d_out.to_array(np.uint16, (h, w, 4)), got)
     assert np.array_equal(d_hist.to_array(np.uint64, (768,)), hist)
     be.close()
+
+
+def test_surface_beyond_4_gib(gpu_lib, refc):
+    """Maximum sizes: a 320 MP frame (20096 x 16000: a stitched panorama; 643 MB of CFA) whose f32 surface is 5.1 GB, so pixel
+    and byte offsets pass 2^32 -- rendered into device memory by the export kernel (one launch, 1.26 M tiles) and by the map
+    kernel, row bands from both sides of the 4 GiB line against the oracle; the histogram counts every pixel.  Then the
+    host read-back of a surface above 4 GiB (band-pipelined, page-locked destination) on the rows around the line."""
+    from tests.gpu_util import DevBuf
+    ra = gpu_lib
+    h, w = 16000, 20096
+    free, total = C.c_size_t(), C.c_size_t()
+    ra._lib.check(ra._lib.lib().rd_device_memory(0, C.byref(free), C.byref(total)))
+    if free.value < 14 * (1 << 30):
+        pytest.skip("needs 14 GiB of free HBM")
+    rng = np.random.default_rng(0x3434)
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = make_pipe(ra, cfa, params, WB_DAYLIGHT, CM_TEST)
+    u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST)
+    row_bytes = w * 16
+    line = (1 << 32) // row_bytes                                # the row that holds byte 2^32
+    bands = ((0, 4), (line - 3, line + 5), (h // 2 + 1, h // 2 + 5), (h - 4, h))
+    exp = {b: refc.render_band(cfa, u, b[0], b[1]) for b in bands}
+    surf = DevBuf(h * row_bytes)
+    hist_dev = DevBuf(768 * 4)
+    assert surf.nbytes > (1 << 32)
+    for kernel in ("quads", "map"):
+        ctx = force_map() if kernel == "map" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            pipe.render_device(w, h, ra.FMT_RGBA_F32, surf.ptr, hist_dev.ptr)
+            ra._lib.check(ra._lib.lib().rd_device_synchronize(0))
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+        for r0, r1 in bands:
+            got = np.empty((r1 - r0, w, 4), np.float32)
+            ra._lib.check(ra._lib.lib().rd_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), C.c_void_p(surf.ptr + r0 * row_bytes), got.nbytes))
+            assert np.array_equal(got.view(np.uint32), exp[(r0, r1)].view(np.uint32)), (kernel, r0)
+        hist = hist_dev.to_array(np.uint32, (3, 256))
+        assert hist.sum(axis=1).tolist() == [h * w] * 3, kernel
+    surf.free(); hist_dev.free()
+    # host read-back above 4 GiB: the f32 surface into page-locked memory, bands around the line and at both ends
+    pin = ra.PinnedBytes(h * row_bytes)
+    out = pin.array.view(np.float32).reshape(h, w, 4)
+    ra._lib.check(ra._lib.lib().rd_render(pipe._h, w, h, ra.FMT_RGBA_F32, C.c_void_p(pin.ptr), pin.nbytes, None))
+    for r0, r1 in bands:
+        assert np.array_equal(out[r0:r1].view(np.uint32), exp[(r0, r1)].view(np.uint32)), ("host", r0)
+    pin.free()
+    pipe.close()
 
 
 def test_matrix_layout_option(gpu_lib, refc, rng):
