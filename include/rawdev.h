@@ -34,7 +34,8 @@ extern "C" {
  * 3: no signature changed.  Host renders no longer serialise on the pipeline (each call takes a render lane; the mutex only
  * guards the uniforms) and a full-resolution render is band-pipelined (see rd_render_full_res_to_bytes); new entry points
  * rd_host_alloc / rd_host_free (page-locked render destinations), rd_measure_hbm (the box's own streaming ceilings),
- * rd_render_full_res_borrow / rd_surface_release (a lent page-locked surface), rd_measure_valu, rd_device_identity, rd_selftest_q8_lut (+ _codes), rd_q8_lut_table. */
+ * rd_render_full_res_borrow / rd_surface_release (a lent page-locked surface), rd_measure_valu, rd_device_identity, rd_selftest_q8_lut (+ _codes), rd_q8_lut_table,
+ * rd_exporter_submit_host (the export ring fed from host memory), rd_selftest_f16_lut (+ _values), rd_f16_lut_tables. */
 #define RD_ABI_VERSION 3
 
 typedef enum rd_status {
@@ -320,6 +321,15 @@ int rd_q8_lut_table(uint32_t *dst, size_t cap_words);
  * (gamma >= 2^-14) where the pinned evaluation decides the half; below that range it always does. */
 int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks);
 int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst);
+/* Round 4: the export kernel takes the RGBA-f16 surface's halves AND its histogram codes from two-level threshold tables in LDS
+ * (binary16(gamma(x)) is a step function with at most one step per 2^13 float encodings for x >= 2^-16 and ONE non-monotone
+ * encoding).  rd_selftest_f16_lut runs the lookup -- including the pinned evaluation of the lanes it
+ * sends there: 0 < x < 2^-16 and that one encoding, counted in *pinned -- against binary16(pinned gamma) and the pinned code
+ * over ALL 2^32 encodings (must report 0 mismatches); rd_selftest_f16_lut_values returns half | code << 16 for a range of
+ * encodings; rd_f16_lut_tables (no device needed) returns the tables: 17410 u16 and 2 x 2177 words. */
+int rd_selftest_f16_lut(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *pinned);
+int rd_selftest_f16_lut_values(int device, uint32_t first_encoding, uint32_t n, uint32_t *dst);
+int rd_f16_lut_tables(uint16_t *fine, size_t cap_fine, uint32_t *coarse, size_t cap_coarse_words);
 
 /* ---- ingest helper (the step before the path; no device needed) ------------------ */
 /* Lossless JPEG (ITU-T T.81 SOF3: Huffman, predictors 1-7, 1-4 interleaved components, precision 2-16, restart

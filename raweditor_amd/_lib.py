@@ -104,6 +104,9 @@ PROTOTYPES = {
     "rd_q8_lut_table": (_I, [_VP, _SZ]),
     "rd_selftest_f16": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64)]),
     "rd_selftest_f16_halves": (_I, [_I, _U32, _U32, _VP]),
+    "rd_selftest_f16_lut": (_I, [_I, C.POINTER(C.c_uint64), C.POINTER(_U32), C.POINTER(C.c_uint64)]),
+    "rd_selftest_f16_lut_values": (_I, [_I, _U32, _U32, _VP]),
+    "rd_f16_lut_tables": (_I, [_VP, _SZ, _VP, _SZ]),
     "rd_ljpeg_decode": (_I, [_VP, _SZ, _VP, _SZ, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "rd_host_alloc": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "rd_host_free": (_I, [_I, _VP]),

@@ -160,6 +160,31 @@ static int rd_q8_lut_ensure(int device)
     return RD_OK;
 }
 
+// The f16 surface's two-level tables (rd_kernels.h, rd_f16_lut_*): the same arrangement, but built (about 40 ms of host time,
+// once per process) only when something is about to render an RGBA-f16 surface with the export kernel.  A pinned function
+// whose shape the lookup does not assume (rd_f16_lut_build's checks) is refused here, loudly.
+static int rd_f16_lut_ensure(int device)
+{
+    static std::mutex mu;
+    static std::vector<uint16_t> fine;
+    static std::vector<uint32_t> coarse;
+    static int built = 1;                                        // 1: not yet; 0: fine; < 0: refused
+    static bool done[64] = {};
+    if (device < 0 || device >= 64) return rd_fail(RD_ERR_NO_DEVICE, "device %d out of range", device);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[device]) return RD_OK;
+    if (built == 1) {
+        fine.assign(RD_F16_LUT_NF + 1u + 128u, 0u);
+        coarse.assign(RD_F16_LUT_NC * 2u + 64u, 0u);
+        built = rd_f16_lut_build(fine.data(), coarse.data());
+    }
+    if (built != 0) return rd_fail(RD_ERR_UNSUPPORTED, "the binary16 threshold tables cannot be built from this gamma (check %d)", built);
+    RD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rd_f16_fine_dev), fine.data(), ((RD_F16_LUT_NF + 1u) / 2u + 64u) * sizeof(uint32_t)));
+    RD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rd_f16_coarse_dev), coarse.data(), coarse.size() * sizeof(uint32_t)));
+    done[device] = true;
+    return RD_OK;
+}
+
 static uint32_t rd_env_u32(const char *name, uint32_t dflt)
 {
     const char *s = getenv(name);

@@ -56,6 +56,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     rc = rd_q8_lut_ensure(device);
+    if (rc == RD_OK && fmt == RD_FMT_RGBA_F16) rc = rd_f16_lut_ensure(device);
     if (rc) return rc;
     rd_batch *b = new (std::nothrow) rd_batch;
     if (!b) return rd_fail(RD_ERR_OOM, "host allocation failed");
@@ -648,6 +649,7 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     rc = rd_q8_lut_ensure(device);
+    if (rc == RD_OK && fmt == RD_FMT_RGBA_F16) rc = rd_f16_lut_ensure(device);
     if (rc) return rc;
     rd_exporter *e = new (std::nothrow) rd_exporter;
     if (!e) return rd_fail(RD_ERR_OOM, "host allocation failed");

@@ -178,6 +178,87 @@ extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint3
     return RD_OK;
 }
 
+// The export kernel's two-level tables for the f16 surface (rd_f16_lut_lookup + the pinned evaluation for the lanes it sends
+// there) against the pinned function, same sweep: tables in LDS, as there.  dst (optional): (half | code << 16) per encoding.
+__global__ void __launch_bounds__(256) rd_f16_lut_sweep(uint32_t base, rd_q8_stats *st, uint32_t *dst)
+{
+    __shared__ uint16_t fine[RD_F16_LUT_NF + 1u];
+    __shared__ uint32_t coarse[RD_F16_LUT_NC * 2u];
+    rd_f16_lut_load(fine, coarse);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = rd_u2f(base + i);
+    uint32_t h, s;
+    bool pinned;
+    float xc;
+    rd_f16_lut_lookup(x, fine, coarse, h, s, pinned, xc);
+    if (pinned) {
+        const float e = rd_gamma_clamp(xc);
+        h = __builtin_bit_cast(uint16_t, (_Float16)e);
+        s = rd_q8(e) << 16;
+    }
+    const float g = rd_gamma_clamp(x);
+    const uint32_t he = __builtin_bit_cast(uint16_t, (_Float16)g), qe = rd_q8(g);
+    if (dst) dst[i] = (h & 0xffffu) | ((s >> 16) << 16);
+    if (!st) return;
+    if (h != he || (s >> 16) != qe) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }   // h, s >> 16 compared whole: no stray high bits
+    if (pinned) atomicAdd(&st->fallbacks, 1ull);
+}
+
+extern "C" int rd_selftest_f16_lut(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *pinned)
+{
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_f16_lut_ensure(device);
+    if (rc) return rc;
+    rd_q8_stats *dst = nullptr, st = { 0, 0, 0xffffffffu, 0 };
+    RD_HIP(hipMalloc((void **)&dst, sizeof st));
+    hipError_t e = hipMemcpy(dst, &st, sizeof st, hipMemcpyHostToDevice);
+    for (uint32_t c = 0; c < 256u && e == hipSuccess; ++c) {    // 256 launches x 2^24 encodings
+        hipLaunchKernelGGL(rd_f16_lut_sweep, dim3(1u << 16), dim3(256), 0, 0, c << 24, dst, (uint32_t *)nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16_lut: %s", hipGetErrorString(e));
+    if (mismatches) *mismatches = st.mismatches;
+    if (first_bad) *first_bad = st.first_bad;
+    if (pinned) *pinned = st.fallbacks;
+    return RD_OK;
+}
+
+extern "C" int rd_selftest_f16_lut_values(int device, uint32_t first_encoding, uint32_t n, uint32_t *dst)
+{
+    if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
+        return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_f16_lut_values: n must be a non-zero multiple of 256 inside the 2^32 encodings");
+    int rc = rd_check_device(device, nullptr);
+    if (rc) return rc;
+    rd_devguard g(device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    rc = rd_f16_lut_ensure(device);
+    if (rc) return rc;
+    uint32_t *dev = nullptr;
+    RD_HIP(hipMalloc((void **)&dev, (size_t)n * 4));
+    hipLaunchKernelGGL(rd_f16_lut_sweep, dim3(n / 256u), dim3(256), 0, 0, first_encoding, (rd_q8_stats *)nullptr, dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(dst, dev, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16_lut_values: %s", hipGetErrorString(e));
+    return RD_OK;
+}
+
+// No device needed: the two tables themselves (fine: RD_F16_LUT_NF u16; coarse: RD_F16_LUT_NC {E, C} pairs), for host-side checks
+// of their construction.  Returns the builder's verdict (0: the shape the lookup assumes) or a negative status.
+extern "C" int rd_f16_lut_tables(uint16_t *fine, size_t cap_fine, uint32_t *coarse, size_t cap_coarse_words)
+{
+    if (!fine || !coarse || cap_fine < RD_F16_LUT_NF + 1u || cap_coarse_words < RD_F16_LUT_NC * 2u)
+        return rd_fail(RD_ERR_INVALID_ARG, "rd_f16_lut_tables: need room for %u u16 and %u words", RD_F16_LUT_NF + 1u, RD_F16_LUT_NC * 2u);
+    const int rc = rd_f16_lut_build(fine, coarse);
+    if (rc) return rd_fail(RD_ERR_UNSUPPORTED, "the binary16 threshold tables cannot be built from this gamma (check %d)", rc);
+    return RD_OK;
+}
+
 extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
 {
     if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))

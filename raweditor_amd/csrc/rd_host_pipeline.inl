@@ -313,6 +313,10 @@ static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, u
     const uint32_t W = p->info.width, H = p->info.height;
     const bool quads = rd_pipeline_uses_quads(p, sh, tw, th, fmt);
     if (!unit1) unit1 = H / 2u + 1u;
+    if (quads && fmt == RD_FMT_RGBA_F16) {                       // the export kernel's binary16 tables: built on first use
+        const int rc = rd_f16_lut_ensure(p->device);
+        if (rc) return rc;
+    }
     uint32_t blocks = 0;
     const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");

@@ -488,6 +488,150 @@ __device__ __forceinline__ void rd_f16_gamma(float x, uint32_t &h, uint32_t &q) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 4, second table: binary16(gamma(x)) AND the 8-bit code from two-level THRESHOLD TABLES in LDS (the export kernel's
+// RGBA-f16 surface; RD_F16_LUT=0 builds the transcendental shortcut above instead, for A/B).
+//
+// h(x) = binary16(rd_gamma_clamp(x)) is a step function of x with 15 360 steps on [0, 1]; tools/f16_monotone.hip walks every
+// encoding: ONE decrease in the whole range (0x3eefb555: the half dips 0x39ab -> 0x39aa for that single encoding), and for
+// x >= 2^-16 no 2^13 consecutive encodings hold more than one step (except that dip's bucket).  With w = clamp01(x) * 2^-110
+// -- exact; [2^-16, 1] lands on exponent fields 1 .. 17, everything smaller is a denormal w -- the tables are
+//   * FINE, one u16 per 2^13 encodings (index bits(w) >> 13 = 0 .. 17408, 34 KiB): ((d - j + 6) << 13) + (0x2000 - t), d = steps
+//     between the start of the bucket's group of eight and the bucket, j = the bucket's place in the group, t = the step's
+//     offset in the bucket (none: 0x2000) -- d - j is in [-6, 0] because a bucket holds at most one step and seven at least one;
+//   * COARSE, one {E, C} pair per 2^16 encodings (index bits(w) >> 16, 17 KiB): E = the 8-bit code's entry exactly as in
+//     rd_q8_lut_build (for this scaling), C = (the half at the group's start) - 6 - 8 * group.
+// Then  half = ((fine + bits(w)) >> 13) + C  -- the add carries "low 13 bits >= t" into bit 13 by itself and the un-masked
+// high bits of w are the bucket index, which C takes out again -- and  s = E + bits(w)  carries the code in bits 16..23:
+// multiply, two shift-and-mask pairs, three adds and a shift per value (16 issue cycles + two LDS reads) for what the
+// shortcut spends 38 + 10 on (v_log, v_exp, midpoint test, subnormal test, code, tie test).  Two kinds of lane take the pinned
+// evaluation instead: 0 < x < 2^-16 (7839 of the steps live down there, and w is a denormal -- or 0 below 2^-40 -- that no
+// longer tells them apart: bits(x) - 1 < bits(2^-16) - 1, one subtraction and one unsigned compare) and the dip's one encoding
+// (one v_cmp_eq).  x = 0 (and every negative or NaN x: the clamp) is w = 0: bucket 0, half 0, code 0.
+// rd_f16_lut_build derives everything from rd_gamma_clamp itself and REFUSES (the library then fails loudly) if a bucket
+// holds two steps or the dips are not exactly the one the kernel tests for; rd_selftest_f16_lut runs the device code against
+// the pinned function for all 2^32 encodings.
+// ---------------------------------------------------------------------------------------------
+#ifndef RD_F16_LUT
+#define RD_F16_LUT 1
+#endif
+#define RD_F16_LUT_SCALE 0x1p-110f           /* 0x08800000 */
+#define RD_F16_LUT_REBIAS 0x37000000u        /* bits(x) - bits(x * 2^-110) for normal results: 110 << 23 */
+#define RD_F16_LUT_NF 17409u                 /* fine buckets 0 .. 0x4400 (w = 2^-110: x = 1.0) */
+#define RD_F16_LUT_NC 2177u                  /* coarse buckets 0 .. 0x880 */
+#define RD_F16_LUT_DIP_X 0x3eefb555u         /* the one encoding where binary16(gamma(x)) is below its predecessor's */
+#define RD_F16_LUT_FINE_BYTES ((RD_F16_LUT_NF + 1u) * 2u)   /* even count: the loader copies dwords */
+
+__device__ uint32_t rd_f16_fine_dev[(RD_F16_LUT_NF + 1u) / 2u + 64u];    // u16 pairs; filled by the host before the first launch
+__device__ uint32_t rd_f16_coarse_dev[RD_F16_LUT_NC * 2u + 64u];         // {E, C} pairs
+
+// binary16 of a float in [0, 1], round to nearest even (host side of the builder; the device converts with v_cvt_f16_f32)
+static inline uint32_t rd_f16_bits_host(float g)
+{
+    const uint32_t b = rd_f2u(g);
+    const int32_t e = (int32_t)(b >> 23) - 127;
+    uint32_t m = (b & 0x7fffffu) | 0x800000u;
+    if (b == 0u) return 0u;
+    if (e < -25) return 0u;                                       // below half of the smallest subnormal
+    uint32_t shift, base;
+    if (e < -14) { shift = (uint32_t)(13 + (-14 - e)); base = 0u; }          // subnormal half: value = m * 2^(e-23), unit 2^-24
+    else { shift = 13u; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1u);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q += 1u;   // a carry out of the fraction moves into the exponent: still right
+    return base + q;
+}
+
+// Host: both tables from the pinned function.  fine: RD_F16_LUT_NF + 1 entries, coarse: 2 * RD_F16_LUT_NC words.  Returns 0,
+// or a negative code when the function's shape is not what the kernel's lookup assumes (-1: two steps in one fine bucket,
+// -2: a field out of range, -3: the set of dips is not { RD_F16_LUT_DIP_X }).
+static inline int rd_f16_lut_build(uint16_t *fine, uint32_t *coarse)
+{
+    auto H = [](uint32_t xb) { return rd_f16_bits_host(rd_gamma_clamp(rd_u2f(xb))); };
+    auto Q = [](uint32_t xb) { return (uint32_t)__builtin_fmaf(rd_gamma_clamp(rd_u2f(xb)), 255.0f, 0.5f); };
+    const uint32_t top = 0x3f800000u, hmax = H(top);              // 0x3c00
+    // thrH[h - 1] = the smallest encoding from which the half is >= h (first up-crossing), dips listed apart
+    uint32_t *thrH = new uint32_t[hmax];
+    uint32_t dips[8], ndips = 0;
+    for (uint32_t h = 1; h <= hmax; ++h) {
+        uint32_t lo = 0u, hi = top;                               // H(lo) < h <= H(hi)
+        while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (H(mid) >= h) hi = mid; else lo = mid; }
+        for (uint32_t k = 1; k <= 8u && hi > k; ++k) if (H(hi - k) >= h) hi -= k, k = 0;   // a dip just below: the first crossing
+        thrH[h - 1u] = hi;
+        for (uint32_t k = 1; k <= 16u && hi + k <= top; ++k)
+            if (H(hi + k) < h) { bool seen = false; for (uint32_t d = 0; d < ndips; ++d) seen |= dips[d] == hi + k; if (!seen && ndips < 8u) dips[ndips++] = hi + k; }
+    }
+    uint32_t thrQ[255];
+    for (uint32_t k = 1; k <= 255u; ++k) {
+        uint32_t lo = 0u, hi = top;
+        while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (Q(mid) >= k) hi = mid; else lo = mid; }
+        thrQ[k - 1u] = hi;
+    }
+    int rc = (ndips == 1u && dips[0] == RD_F16_LUT_DIP_X) ? 0 : -3;
+    const uint32_t first_normal = 1u << 10;                       // fine bucket of w = 2^-126 (x = 2^-16)
+    for (uint32_t i = 0; i <= RD_F16_LUT_NF; ++i) fine[i] = 0u;
+    for (uint32_t c = 0; c < RD_F16_LUT_NC; ++c) { coarse[2u * c] = 0u; coarse[2u * c + 1u] = 0u; }
+    uint32_t kh = 0, kq = 0;
+    for (uint32_t c = first_normal >> 3; c < RD_F16_LUT_NC; ++c) {
+        const uint32_t xs_c = (c << 16) + RD_F16_LUT_REBIAS;
+        while (kh < hmax && thrH[kh] <= xs_c) ++kh;               // kh = the half at the group's start
+        while (kq < 255u && thrQ[kq] <= xs_c) ++kq;
+        uint32_t tq = 0x10000u;
+        if (kq < 255u && thrQ[kq] - xs_c < 0x10000u) tq = thrQ[kq] - xs_c;
+        coarse[2u * c] = (kq << 16) + (0x10000u - tq) - (c << 16);
+        coarse[2u * c + 1u] = kh - 6u - 8u * c;
+        uint32_t k = kh;
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t i = c * 8u + j;
+            if (i >= RD_F16_LUT_NF) break;
+            const uint32_t xs = (i << 13) + RD_F16_LUT_REBIAS;
+            while (k < hmax && thrH[k] <= xs) ++k;
+            uint32_t t = 0x2000u;
+            if (k < hmax && thrH[k] - xs < 0x2000u) {
+                t = thrH[k] - xs;
+                if (k + 1u < hmax && thrH[k + 1u] - xs < 0x2000u && rc == 0) rc = -1;
+            }
+            const int32_t field = (int32_t)(k - kh) - (int32_t)j + 6;
+            if ((field < 0 || field > 6) && rc == 0) rc = -2;
+            fine[i] = (uint16_t)(((uint32_t)field << 13) + (0x2000u - t));
+        }
+    }
+    delete[] thrH;
+    return rc;
+}
+
+#define RD_F16_LUT_DIP_W (RD_F16_LUT_DIP_X - RD_F16_LUT_REBIAS)
+
+// half: binary16(gamma(x)) as an integer (bits 16..31 zero); s: the 8-bit code in bits 16..23 (rd_q8_lut_bits' format);
+// pinned: this lane needs the pinned evaluation instead (0 < x < 2^-16, or the dip).  fine / coarse: the LDS copies.
+// xc: clamp01(x), what the pinned evaluation of such a lane starts from (the same result as from x, and x's only use is then
+// the clamp, which the compiler folds into the instruction that produced x).
+__device__ __forceinline__ void rd_f16_lut_lookup(float x, const uint16_t *fine, const uint32_t *coarse, uint32_t &half, uint32_t &s, bool &pinned, float &xc)
+{
+    typedef uint32_t rd_u2v __attribute__((ext_vector_type(2)));
+    xc = __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f);                 // negative, NaN -> 0; > 1 -> 1
+    const float w = xc * RD_F16_LUT_SCALE;                       // exact
+    const uint32_t wb = rd_f2u(w);
+    uint32_t t1 = wb >> 12, t2 = wb >> 13;
+    asm("" : "+v"(t1), "+v"(t2));                                 // keep them shifts (v_bfe_u32 issues at half rate)
+    const uint32_t fe = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(fine) + (t1 & 0xfffeu));
+    const rd_u2v ce = *reinterpret_cast<const rd_u2v *>(reinterpret_cast<const char *>(coarse) + (t2 & 0xfff8u));
+    uint32_t sum = fe + wb;
+    asm("" : "+v"(sum));
+    half = (sum >> 13) + ce.y;
+    s = ce.x + wb;
+    pinned = (rd_f2u(xc) - 1u) < 0x377fffffu || wb == RD_F16_LUT_DIP_W;           // 0 < xc < 2^-16 (one unsigned compare), or the dip
+}
+
+// The export kernel copies both tables into LDS once per workgroup.
+__device__ __forceinline__ void rd_f16_lut_load(uint16_t *fine, uint32_t *coarse)
+{
+    uint32_t *f32 = reinterpret_cast<uint32_t *>(fine);
+    for (uint32_t i = threadIdx.x; i < (RD_F16_LUT_NF + 1u) / 2u; i += blockDim.x) f32[i] = rd_f16_fine_dev[i];
+    for (uint32_t i = threadIdx.x; i < RD_F16_LUT_NC * 2u; i += blockDim.x) coarse[i] = rd_f16_coarse_dev[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Histogram: RD_HK private copies of every bin in LDS, copy = lane % RD_HK, so a flat frame (all 64
 // lanes in one bin) serialises 64/RD_HK-deep on an address instead of 64-deep.  RD_HK = 8 keeps the
 // table at 24 KiB, which together with the 48 KiB store-transpose stage lets TWO 1024-thread
@@ -728,23 +872,27 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 #undef RD_PARK
     };
 #if defined(RD_COLOUR_HOOK_HEADER) || defined(RD_NO_Q8_SHORTCUT)
-    constexpr bool Q8LUT = false;
+    constexpr bool Q8LUT = false, F16LUT = false;
 #else
     constexpr bool Q8LUT = (RD_Q8_LUT != 0) && (FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8);   // codes from the LDS threshold table
+    constexpr bool F16LUT = (RD_F16_LUT != 0) && FMT == RD_FMT_RGBA_F16;                         // halves and codes from the two-level tables
 #endif
     // lane constants of the gamma shortcuts (rd_kc), in VGPRs for the same reason; the asm keeps them there
     rd_kc kc = { 255.0f, RD_F16_KA / 64.0f, RD_F16_KB / 64.0f };
-    if constexpr (FMT != RD_FMT_RGBA_F32 && !Q8LUT) {
+    if constexpr (FMT != RD_FMT_RGBA_F32 && !Q8LUT && !F16LUT) {
         asm volatile("" : "+v"(kc.k255));
         if constexpr (FMT == RD_FMT_RGBA_F16) asm volatile("" : "+v"(kc.f16_ka), "+v"(kc.f16_kb));
     }
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
     __shared__ uint32_t qlut[Q8LUT ? RD_Q8_LUT_WORDS : 1];
+    __shared__ uint16_t hfine[F16LUT ? RD_F16_LUT_NF + 1u : 2];
+    __shared__ uint32_t hcoarse[F16LUT ? RD_F16_LUT_NC * 2u : 2];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     __shared__ rd_f4 pf_dump[BURST ? 64 : 1];                    // where the LDS-DMA sweeps land (never read)
     if constexpr (Q8LUT) rd_q8_lut_load(qlut);
+    if constexpr (F16LUT) rd_f16_lut_load(hfine, hcoarse);
     if (HIST) rd_hist_zero(lh);
     if constexpr (FMT == RD_FMT_RGBA_F32) {
         // The store stage holds [lane][c1, c2, c3] as RGBA; alpha is 1.0 for every pixel of every tile, so it is written
@@ -878,13 +1026,44 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         rd_rgb c1 = { 0.0f, 0.0f, 0.0f }, c2 = c1, c3 = c1;
         const uint32_t hbase = rd_hist_base(copy);               // loop-invariant: hoisted
         auto count = [&](uint32_t qr, uint32_t qg, uint32_t qb, uint32_t inc) {      // one pixel's codes into the histogram
-            if constexpr (Q8LUT) rd_hist_add_b2(lh, copy * 4u, qr, qg, qb, inc);
+            if constexpr (Q8LUT || F16LUT) rd_hist_add_b2(lh, copy * 4u, qr, qg, qb, inc);
             else if constexpr (BITS) rd_hist_add_bits(lh, hbase, qr, qg, qb, inc);
             else rd_hist_add(lh, copy, qr, qg, qb, inc);
         };
         auto code = [&](float v) -> uint32_t {                   // the 8-bit code of a linear value, as the surface's encoding of it
             if constexpr (Q8LUT) return rd_q8_lut_bits(v, qlut);
             else return rd_q8_gamma_bits(v, kc);
+        };
+        // F16LUT: binary16 of one value as an integer + its code (bits 16..23 of q), both from the tables; the rare lane
+        // below the tables' domain (or on the dip) takes the pinned evaluation
+        auto half_of = [&](float v, uint32_t &q) -> uint32_t {
+            uint32_t h = 0u;
+            if constexpr (F16LUT) {
+                bool pinned;
+                float vc;
+                rd_f16_lut_lookup(v, hfine, hcoarse, h, q, pinned, vc);
+                if (pinned) {
+                    const float e = rd_gamma_clamp(vc);
+                    h = __builtin_bit_cast(uint16_t, (_Float16)e);
+                    q = rd_q8(e) << 16;
+                }
+            }
+            return h;
+        };
+        // three values at once: six LDS reads in flight behind one wait, and ONE branch for the rare lanes instead of three
+        auto halves_of = [&](float v0, float v1, float v2, uint32_t &h0, uint32_t &h1, uint32_t &h2, uint32_t &q0, uint32_t &q1, uint32_t &q2) {
+            if constexpr (F16LUT) {
+                bool p0, p1, p2;
+                float c0, c1, c2;
+                rd_f16_lut_lookup(v0, hfine, hcoarse, h0, q0, p0, c0);
+                rd_f16_lut_lookup(v1, hfine, hcoarse, h1, q1, p1, c1);
+                rd_f16_lut_lookup(v2, hfine, hcoarse, h2, q2, p2, c2);
+                if (p0 || p1 || p2) {
+                    if (p0) { const float e = rd_gamma_clamp(c0); h0 = __builtin_bit_cast(uint16_t, (_Float16)e); q0 = rd_q8(e) << 16; }
+                    if (p1) { const float e = rd_gamma_clamp(c1); h1 = __builtin_bit_cast(uint16_t, (_Float16)e); q1 = rd_q8(e) << 16; }
+                    if (p2) { const float e = rd_gamma_clamp(c2); h2 = __builtin_bit_cast(uint16_t, (_Float16)e); q2 = rd_q8(e) << 16; }
+                }
+            } else { h0 = h1 = h2 = 0u; (void)v0; (void)v1; (void)v2; (void)q0; (void)q1; (void)q2; }
         };
         bool separable = false;                                  // wave-uniform
 #ifndef RD_COLOUR_HOOK_HEADER
@@ -904,6 +1083,16 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                     if (has_a) count(q1r, q1g, q1b, 2u);
                     if (has_b) { count(q2r, q2g, q2b, 1u); count(q3r, q3g, q3b, 1u); }
                 }
+            } else if constexpr (H16 && F16LUT) {
+                uint32_t hr, hg, hb;
+                halves_of(v[0], v[1], v[3], hr, hg, hb, q1r, q1g, q1b);
+                ha0 = hr | (hg << 16); ha1 = hb | 0x3c000000u;                 // (r, g), (b, 1.0)
+                if (HIST && valid && has_a) count(q1r, q1g, q1b, 2u);
+                const uint32_t hg2 = half_of(v[2], q2g), hb2 = half_of(v[4], q2b);
+                q2r = q1r; q3r = q1r; q3g = q2g; q3b = q1b;
+                hb0 = hr | (hg2 << 16); hb1 = hb2 | 0x3c000000u;
+                hc0 = hb0; hc1 = ha1;
+                if (HIST && valid && has_b) { count(q2r, q2g, q2b, 1u); count(q3r, q3g, q3b, 1u); }
             } else if constexpr (H16) {
                 const float er = rd_f16_gamma_value<HIST>(v[0], kc, q1r), eg = rd_f16_gamma_value<HIST>(v[1], kc, q1g);
                 const float eb = rd_f16_gamma_value<HIST>(v[3], kc, q1b);
@@ -931,6 +1120,14 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             q1r = code(c1.r); q1g = code(c1.g); q1b = code(c1.b);
             q2r = code(c2.r); q2g = code(c2.g); q2b = code(c2.b);
             q3r = code(c3.r); q3g = code(c3.g); q3b = code(c3.b);
+        } else if constexpr (H16 && F16LUT) {                     // triple by triple, as below
+            uint32_t hr, hg, hb;                                  // (the codes are counted after the third triple, below)
+            halves_of(c1.r, c1.g, c1.b, hr, hg, hb, q1r, q1g, q1b);
+            ha0 = hr | (hg << 16); ha1 = hb | 0x3c000000u;
+            halves_of(c2.r, c2.g, c2.b, hr, hg, hb, q2r, q2g, q2b);
+            hb0 = hr | (hg << 16); hb1 = hb | 0x3c000000u;
+            halves_of(c3.r, c3.g, c3.b, hr, hg, hb, q3r, q3g, q3b);
+            hc0 = hr | (hg << 16); hc1 = hb | 0x3c000000u;
         } else if constexpr (H16) {                               // triple by triple: halves packed and codes counted at once,
             float er, eg, eb;                                     // so that at most one triple's values are live
             er = rd_f16_gamma_value<HIST>(c1.r, kc, q1r); eg = rd_f16_gamma_value<HIST>(c1.g, kc, q1g); eb = rd_f16_gamma_value<HIST>(c1.b, kc, q1b);
@@ -962,7 +1159,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
             q3r = rd_q8(c3.r); q3g = rd_q8(c3.g); q3b = rd_q8(c3.b);
         }
-        if (HIST && valid && !H16 && !F32T) {
+        if (HIST && valid && (!H16 || F16LUT) && !F32T) {
             if (has_a) count(q1r, q1g, q1b, 2u);
             if (has_b) { count(q2r, q2g, q2b, 1u); count(q3r, q3g, q3b, 1u); }
         }

@@ -123,3 +123,46 @@ def test_f16_shortcut_against_the_oracle(gpu_lib, refc):
     for first in firsts:
         bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
         assert np.array_equal(halves(first, 256), oracle_halves(bits)), hex(first)
+
+
+def test_f16_tables_equal_binary16_of_the_pinned_gamma_for_every_float(gpu_lib):
+    """Round 4: the export kernel's RGBA-f16 surface takes halves AND histogram codes from two-level threshold tables in LDS
+    (rd_f16_lut_lookup); the lanes it sends to the pinned evaluation are 0 < x < 2^-16 and the one non-monotone encoding.  For
+    all 2^32 encodings: half == binary16(rd_gamma_clamp(x)), code == the pinned code, no stray high bits."""
+    from raweditor_amd import _lib
+    bad, first, pinned = C.c_uint64(), C.c_uint32(), C.c_uint64()
+    _lib.check(_lib.lib().rd_selftest_f16_lut(0, C.byref(bad), C.byref(first), C.byref(pinned)))
+    assert bad.value == 0, f"{bad.value} encodings differ, first 0x{first.value:08x}"
+    assert pinned.value == 0x37800000 - 1 + 1          # the encodings of (0, 2^-16), and the dip
+
+
+def test_f16_tables_against_the_oracle(gpu_lib, refc):
+    """The same lookup against the ORACLE's pow -> clamp -> binary16 / 8-bit pack: the special encodings, the dip and its
+    neighbours, the edge of the tables' domain (2^-16), the bright half densely, every exponent, and windows around steps."""
+    from raweditor_amd import _lib
+
+    def values(first, n):
+        out = np.empty(n, np.uint32)
+        _lib.check(_lib.lib().rd_selftest_f16_lut_values(0, first, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def oracle(bits):
+        L = refc.lib()
+        x = bits.astype(np.uint32).view(np.float32)
+        g = np.empty_like(x)
+        for i, v in enumerate(x):
+            g[i] = L.ref_powf(C.c_float(v), C.c_float(np.float32(0.45454547)), 0)
+        g = np.minimum(np.where(g > 0, g, np.float32(0)).astype(np.float32), np.float32(1))
+        return refc.pack_f16(g).view(np.uint16).astype(np.uint32) | (refc.pack_u8(g).astype(np.uint32) << 16)
+
+    rng = np.random.default_rng(17)
+    firsts = [0x00000000, 0x007fff00, 0x00800000, 0x377fff00, 0x37800000, 0x3eefb500, 0x3f7fff00, 0x3f800000, 0x7f7fff00,
+              0x7f800000, 0x7fc00000, 0x80000000, 0xbf800000, 0xff800000, 0xffffff00]
+    firsts += [int(v) // 256 * 256 for v in rng.integers(0x3c000000, 0x3f800000, 160, dtype=np.uint64)]
+    firsts += [(e << 23) + (int(m) // 256 * 256) for e in range(1, 255) for m in rng.integers(0, 1 << 23, 1)]
+    firsts += [int(v) // 256 * 256 for v in rng.integers(0, 2**32 - 256, 64, dtype=np.uint64)]
+    # windows on fine-bucket boundaries (2^13 encodings) inside the domain: where one table entry hands over to the next
+    firsts += [((int(v) >> 13) << 13) - 128 for v in rng.integers(0x37800000 + 8192, 0x3f800000, 96, dtype=np.uint64)]
+    for first in firsts:
+        bits = np.arange(first, first + 256, dtype=np.uint64).astype(np.uint32)
+        assert np.array_equal(values(first, 256), oracle(bits)), hex(first)

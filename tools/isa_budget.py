@@ -90,7 +90,7 @@ def build_stage_table():
     rng(k, "rd_colour_separable(const rd_ku &u", "rd_colour_m(const rd_ku &u", "rd_kernels.h", "separable stack")
     rng(k, "rd_norm(uint32_t raw", "// Rgba8Unorm quantisation (pipeline.rs:322)", "rd_kernels.h", "unpack + convert (u16 -> f32 / 4096)")
     rng(k, "// Rgba8Unorm quantisation (pipeline.rs:322)", "#define RD_F16_KA", "rd_kernels.h", "gamma shortcut -> 8-bit code (rd_q8_gamma)")
-    rng(k, "#define RD_F16_KA", "// Histogram: RD_HK private copies", "rd_kernels.h", "gamma shortcut -> binary16 (rd_f16_gamma)")
+    rng(k, "#define RD_F16_KA", "// Histogram: RD_HK private copies", "rd_kernels.h", "binary16 + code: shortcut (rd_f16_gamma) / tables (rd_f16_lut_*)")
     rng(k, "rd_hist_zero(uint32_t *lh)", "// Surface stores.  FMT is an rd_format", "rd_kernels.h", "histogram (addresses + LDS atomics)")
     rng(k, "auto adopt = [&]", "typedef uint32_t rd_u4 __attribute__", "rd_kernels.h", "frame change: uniforms (adopt)")
     rng(k, "auto split = [&]", "uint32_t unit, qt, fr_c, tin0;", "rd_kernels.h", "tile bookkeeping (tickets, tile -> row / column)")
@@ -210,10 +210,13 @@ def main():
         operands = body[len(op):].strip()
         insts.append({"op": op, "operands": operands, "label": cur_label, "loc": cur_loc, "text": body})
 
-    # loops = backward branches; the main loop is the one enclosing the most instructions
+    # loops = backward branches on a WAVE-UNIFORM condition (scc / vcc); the main loop is the one enclosing the most
+    # instructions.  Not s_branch (block layout) and not s_cbranch_exec*: those are the returns of out-of-line blocks that
+    # hipcc places behind the loop -- the rare pinned evaluation of a few lanes jumps back INTO the body from there, which
+    # would otherwise read as a "loop" from the body's top to the end of the kernel.
     best = None
     for i, ins in enumerate(insts):
-        if ins["op"].startswith("s_cbranch"):                 # (an unconditional backward s_branch is block layout, not a loop)
+        if ins["op"].startswith(("s_cbranch_scc", "s_cbranch_vcc")):
             tgt = ins["operands"].strip()
             if tgt in labels and labels[tgt] <= i:
                 span = (labels[tgt], i)
