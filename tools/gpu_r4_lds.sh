@@ -1,32 +1,35 @@
 #!/bin/bash
-# round 4: is LDS the next limiter of the RGBA8 kernel now that nine table gathers per lane and tile sit beside the nine histogram
-# atomics?  SQ LDS counters of the threshold-table build and of the -DRD_Q8_LUT=0 build, noise and gradient data.
+# round 4: is LDS the next limiter of the RGBA8 (or, with "f16" as the second argument, the RGBA-f16) kernel now that the table gathers
+# sit beside the nine histogram atomics per lane and tile?  SQ LDS counters of the threshold-table build and of the build without
+# it (-DRD_Q8_LUT=0 / -DRD_F16_LUT=0), noise and gradient data.      bash tools/gpu_r4_lds.sh [tag] [u8|f16]
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-r4lds}; mkdir -p "$OUT"
+FMT=${2:-u8}
+if [ "$FMT" = f16 ]; then NOLUT=$ROOT/tools/librawdev_r4nof16lut.so; KERNEL="rd_develop_batch<1"; else NOLUT=$ROOT/tools/librawdev_r4nolut.so; KERNEL="rd_develop_batch<2"; fi
 cd /tmp && export TMPDIR=/tmp
-BENCH="--format u8 --ring 32 --steps 2 --warmup 1 --frames 32 --no-cpu-baseline --no-alt-math --no-extra --no-box"
+BENCH="--format $FMT --ring 32 --steps 2 --warmup 1 --frames 32 --no-cpu-baseline --no-alt-math --no-extra --no-box"
 for lib in lut nolut; do
   for data in uniform gradient; do
     name=${lib}_${data}
-    ( [ $lib = nolut ] && export RAWDEV_LIB=$ROOT/tools/librawdev_r4nolut.so
+    ( [ $lib = nolut ] && export RAWDEV_LIB=$NOLUT
       timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/$name" -- \
         python3 "$ROOT/bench.py" $BENCH --data $data > "$OUT/$name.log" 2>&1 )
     rc=$?; echo "$name rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
   done
 done
 cd "$ROOT"
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$KERNEL" <<'PY'
 import csv, glob, sys, collections
-out=sys.argv[1]
+out=sys.argv[1]; KERNEL=sys.argv[2]
 for name in ("nolut_uniform","lut_uniform","nolut_gradient","lut_gradient"):
     fs=glob.glob(f"{out}/{name}/*/*counter_collection.csv")
     if not fs: print(name, "no counters"); continue
     acc=collections.defaultdict(float); n=0
     for r in csv.DictReader(open(fs[0])):
-        if "rd_develop_batch<2" not in r["Kernel_Name"]: continue
+        if KERNEL not in r["Kernel_Name"]: continue
         acc[r["Counter_Name"]]+=float(r["Counter_Value"])
     ks=glob.glob(f"{out}/{name}/*/*kernel_trace.csv")
-    durs=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(ks[0])) if "rd_develop_batch<2" in r["Kernel_Name"]]
+    durs=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(ks[0])) if KERNEL in r["Kernel_Name"]]
     launches=len(durs); frames=launches*32
     if not launches: print(name, "no launches"); continue
     us=sum(durs)/1e3/frames
