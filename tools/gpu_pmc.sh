@@ -5,9 +5,11 @@
 # frames; config 5: 8 frames, ring of 4).  tools/parse_pmc.py turns the result into profiles/pmc_traffic.json and a
 # summary; the gfx950 corrections (FETCH_SIZE x2 for 16-B LDS-DMA reads, calibrated on a known volume for 4-B loads)
 # are applied there.
-#   tools/gpu_pmc.sh [tag]      (run from the repository root on the GPU box)
+#   tools/gpu_pmc.sh [tag] [only]      (run from the repository root on the GPU box; only = "f16": just the f16 surface's passes,
+#                                       e.g. after a change to that kernel -- the other passes of the tag stay as they are)
 set -u
 TAG=${1:-r02}
+ONLY=${2:-all}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
@@ -16,6 +18,7 @@ BENCH="--steps 2 --warmup 1 --frames 32 --no-cpu-baseline --no-alt-math --no-ext
 C5="--width 11648 --height 8736 --format f16 --row-bands 8 --frames 8 --ring 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-extra"
 pass() {   # name, env assignments ("-" for none), counters (comma separated), bench arguments...
   local name=$1 envs=$2 ctrs=$3; shift 3
+  if [ "$ONLY" = f16 ]; then case $name in f16_*|c5_*) ;; *) return 0;; esac; fi
   echo "== $name [$envs] $ctrs"
   ( [ "$envs" != "-" ] && export $envs
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d "$OUT/$name" -- \
