@@ -53,7 +53,7 @@ extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_
 // The export kernel's threshold table (rd_q8_lut_bits) against the pinned evaluation, same sweep: the table in LDS, as there.
 __global__ void __launch_bounds__(256) rd_q8_lut_sweep(uint32_t base, rd_q8_stats *st, uint8_t *codes)
 {
-    __shared__ uint32_t lut[RD_Q8_LUT_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[RD_Q8_LUT_LDS_WORDS];
     rd_q8_lut_load(lut);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const float x = rd_u2f(base + i);
@@ -182,8 +182,8 @@ extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint3
 // there) against the pinned function, same sweep: tables in LDS, as there.  dst (optional): (half | code << 16) per encoding.
 __global__ void __launch_bounds__(256) rd_f16_lut_sweep(uint32_t base, rd_q8_stats *st, uint32_t *dst)
 {
-    __shared__ uint16_t fine[RD_F16_LUT_NF + 1u];
-    __shared__ uint32_t coarse[RD_F16_LUT_NC * 2u];
+    __shared__ __attribute__((aligned(16))) uint16_t fine[RD_F16_LUT_FINE_LDS];
+    __shared__ __attribute__((aligned(16))) uint32_t coarse[RD_F16_LUT_COARSE_LDS];
     rd_f16_lut_load(fine, coarse);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const float x = rd_u2f(base + i);

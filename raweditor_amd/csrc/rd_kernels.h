@@ -382,10 +382,11 @@ __device__ __forceinline__ uint32_t rd_q8_gamma(float x)
 #define RD_Q8_LUT 1
 #endif
 #define RD_Q8_LUT_WORDS 3969u                /* buckets 0 .. 0xF80 (w = 2^-96: x = 1.0) */
+#define RD_Q8_LUT_LDS_WORDS 3972u            /* the LDS copy, padded to whole 16-byte loads */
 #define RD_Q8_LUT_SCALE 0x1p-96f             /* 0x0f800000 */
 #define RD_Q8_LUT_REBIAS 0x30000000u         /* bits(x) - bits(x * 2^-96) for normal results: 96 << 23 */
 
-__device__ uint32_t rd_q8_lut_dev[RD_Q8_LUT_WORDS + 63u];       // filled by the host before the first launch (rawdev.hip)
+__device__ __attribute__((aligned(16))) uint32_t rd_q8_lut_dev[RD_Q8_LUT_WORDS + 63u];       // filled by the host before the first launch (rawdev.hip)
 
 // Host: the table from the pinned function.  thr[k-1] = the smallest encoding whose code is >= k (bisection: q is monotone).
 static inline void rd_q8_lut_build(uint32_t *lut /* RD_Q8_LUT_WORDS */)
@@ -422,7 +423,10 @@ __device__ __forceinline__ uint32_t rd_q8_lut_bits(float x, const uint32_t *lut)
 // The export kernel copies the table into LDS once per workgroup.
 __device__ __forceinline__ void rd_q8_lut_load(uint32_t *lut)
 {
-    for (uint32_t i = threadIdx.x; i < RD_Q8_LUT_WORDS; i += blockDim.x) lut[i] = rd_q8_lut_dev[i];
+    typedef uint32_t rd_u4v __attribute__((ext_vector_type(4)));       // 16 bytes per lane: a quarter of the instructions (the load is
+    const rd_u4v *src = reinterpret_cast<const rd_u4v *>(rd_q8_lut_dev);   // paid by every launch, however small)
+    rd_u4v *dst = reinterpret_cast<rd_u4v *>(lut);
+    for (uint32_t i = threadIdx.x; i < RD_Q8_LUT_LDS_WORDS / 4u; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 
@@ -519,10 +523,11 @@ __device__ __forceinline__ void rd_f16_gamma(float x, uint32_t &h, uint32_t &q) 
 #define RD_F16_LUT_NF 17409u                 /* fine buckets 0 .. 0x4400 (w = 2^-110: x = 1.0) */
 #define RD_F16_LUT_NC 2177u                  /* coarse buckets 0 .. 0x880 */
 #define RD_F16_LUT_DIP_X 0x3eefb555u         /* the one encoding where binary16(gamma(x)) is below its predecessor's */
-#define RD_F16_LUT_FINE_BYTES ((RD_F16_LUT_NF + 1u) * 2u)   /* even count: the loader copies dwords */
+#define RD_F16_LUT_FINE_LDS 17416u            /* u16 entries of the LDS copy: RD_F16_LUT_NF padded to whole 16-byte loads */
+#define RD_F16_LUT_COARSE_LDS 4356u          /* words of the LDS copy: 2 * RD_F16_LUT_NC padded likewise */
 
-__device__ uint32_t rd_f16_fine_dev[(RD_F16_LUT_NF + 1u) / 2u + 64u];    // u16 pairs; filled by the host before the first launch
-__device__ uint32_t rd_f16_coarse_dev[RD_F16_LUT_NC * 2u + 64u];         // {E, C} pairs
+__device__ __attribute__((aligned(16))) uint32_t rd_f16_fine_dev[(RD_F16_LUT_NF + 1u) / 2u + 64u];    // u16 pairs; filled by the host before the first launch
+__device__ __attribute__((aligned(16))) uint32_t rd_f16_coarse_dev[RD_F16_LUT_NC * 2u + 64u];         // {E, C} pairs
 
 // binary16 of a float in [0, 1], round to nearest even (host side of the builder; the device converts with v_cvt_f16_f32)
 static inline uint32_t rd_f16_bits_host(float g)
@@ -625,9 +630,11 @@ __device__ __forceinline__ void rd_f16_lut_lookup(float x, const uint16_t *fine,
 // The export kernel copies both tables into LDS once per workgroup.
 __device__ __forceinline__ void rd_f16_lut_load(uint16_t *fine, uint32_t *coarse)
 {
-    uint32_t *f32 = reinterpret_cast<uint32_t *>(fine);
-    for (uint32_t i = threadIdx.x; i < (RD_F16_LUT_NF + 1u) / 2u; i += blockDim.x) f32[i] = rd_f16_fine_dev[i];
-    for (uint32_t i = threadIdx.x; i < RD_F16_LUT_NC * 2u; i += blockDim.x) coarse[i] = rd_f16_coarse_dev[i];
+    typedef uint32_t rd_u4v __attribute__((ext_vector_type(4)));       // 16 bytes per lane (see rd_q8_lut_load)
+    rd_u4v *f = reinterpret_cast<rd_u4v *>(fine), *c = reinterpret_cast<rd_u4v *>(coarse);
+    const rd_u4v *fs = reinterpret_cast<const rd_u4v *>(rd_f16_fine_dev), *cs = reinterpret_cast<const rd_u4v *>(rd_f16_coarse_dev);
+    for (uint32_t i = threadIdx.x; i < RD_F16_LUT_FINE_LDS / 8u; i += blockDim.x) f[i] = fs[i];
+    for (uint32_t i = threadIdx.x; i < RD_F16_LUT_COARSE_LDS / 4u; i += blockDim.x) c[i] = cs[i];
     __syncthreads();
 }
 
@@ -885,9 +892,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     }
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
-    __shared__ uint32_t qlut[Q8LUT ? RD_Q8_LUT_WORDS : 1];
-    __shared__ uint16_t hfine[F16LUT ? RD_F16_LUT_NF + 1u : 2];
-    __shared__ uint32_t hcoarse[F16LUT ? RD_F16_LUT_NC * 2u : 2];
+    __shared__ __attribute__((aligned(16))) uint32_t qlut[Q8LUT ? RD_Q8_LUT_LDS_WORDS : 4];
+    __shared__ __attribute__((aligned(16))) uint16_t hfine[F16LUT ? RD_F16_LUT_FINE_LDS : 8];
+    __shared__ __attribute__((aligned(16))) uint32_t hcoarse[F16LUT ? RD_F16_LUT_COARSE_LDS : 4];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     __shared__ rd_f4 pf_dump[BURST ? 64 : 1];                    // where the LDS-DMA sweeps land (never read)
