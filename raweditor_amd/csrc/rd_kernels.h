@@ -548,19 +548,22 @@ static inline uint32_t rd_f16_bits_host(float g)
 
 // Host: both tables from the pinned function.  fine: RD_F16_LUT_NF + 1 entries, coarse: 2 * RD_F16_LUT_NC words.  Returns 0,
 // or a negative code when the function's shape is not what the kernel's lookup assumes (-1: two steps in one fine bucket,
-// -2: a field out of range, -3: the set of dips is not { RD_F16_LUT_DIP_X }).
+// -2: a field out of range, -3: the set of dips is not { RD_F16_LUT_DIP_X }, -4: out of memory).
 static inline int rd_f16_lut_build(uint16_t *fine, uint32_t *coarse)
 {
     auto H = [](uint32_t xb) { return rd_f16_bits_host(rd_gamma_clamp(rd_u2f(xb))); };
     auto Q = [](uint32_t xb) { return (uint32_t)__builtin_fmaf(rd_gamma_clamp(rd_u2f(xb)), 255.0f, 0.5f); };
     const uint32_t top = 0x3f800000u, hmax = H(top);              // 0x3c00
     // thrH[h - 1] = the smallest encoding from which the half is >= h (first up-crossing), dips listed apart
-    uint32_t *thrH = new uint32_t[hmax];
+    uint32_t *thrH = new (std::nothrow) uint32_t[hmax];
+    if (!thrH) return -4;
     uint32_t dips[8], ndips = 0;
     for (uint32_t h = 1; h <= hmax; ++h) {
         uint32_t lo = 0u, hi = top;                               // H(lo) < h <= H(hi)
         while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (H(mid) >= h) hi = mid; else lo = mid; }
-        for (uint32_t k = 1; k <= 8u && hi > k; ++k) if (H(hi - k) >= h) hi -= k, k = 0;   // a dip just below: the first crossing
+        for (uint32_t k = 1; k <= 8u && hi > k;) {              // a dip just below: take the FIRST crossing
+            if (H(hi - k) >= h) { hi -= k; k = 1; } else ++k;
+        }
         thrH[h - 1u] = hi;
         for (uint32_t k = 1; k <= 16u && hi + k <= top; ++k)
             if (H(hi + k) < h) { bool seen = false; for (uint32_t d = 0; d < ndips; ++d) seen |= dips[d] == hi + k; if (!seen && ndips < 8u) dips[ndips++] = hi + k; }
