@@ -61,6 +61,31 @@ RD_HD float rd_exp2f_core(float z)
     return rd_u2f(rd_f2u(p) + (rd_f2u(t) << 23));
 }
 
+// The same value as rd_exp2f_core(z) for z in (-126, 127), as the PRODUCT p * 2^n instead of an add into p's exponent field:
+// 2^n = bits 0x3f800000 + (n << 23) is a normal float there, and multiplying the normal p by a power of two that keeps the
+// result normal is exact -- the same bits.  What it buys on the device: the multiply takes the [0, 1] clamp as an output
+// modifier, so rd_gamma_clamp's min(., 1) costs nothing (v_lshl_add_u32 + v_mul_f32 clamp instead of v_lshl_add_u32 + v_min_u32).
+RD_HD float rd_exp2f_core_clamp01(float z)
+{
+    const float magic = 12582912.0f;
+    float t = z + magic;
+    float n = t - magic;
+    float f = z - n;
+    float p = 0x1.43e9d6p-13f;
+    p = __builtin_fmaf(p, f, 0x1.5f4e2ep-10f);
+    p = __builtin_fmaf(p, f, 0x1.3b2a72p-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6aec2p-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebfbep-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e43p-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    const float r = p * rd_u2f((rd_f2u(t) << 23) + 0x3f800000u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(r, 0.0f, 1.0f);            // folded into the multiply's clamp modifier (r is positive or NaN)
+#else
+    return r < 1.0f ? r : 1.0f;                                // (a NaN r belongs to an x the caller replaces by 0)
+#endif
+}
+
 // Full-domain 2^z: NaN -> NaN, z >= 128 -> +inf, z < -126 -> 0 (sub-FLT_MIN results flush).
 RD_HD float rd_exp2f(float z)
 {
@@ -77,7 +102,6 @@ RD_HD float rd_exp2f(float z)
 RD_HD float rd_gamma_clamp(float x)
 {
     float z = RD_INV_GAMMA * rd_log2f(x);
-    uint32_t v = rd_f2u(rd_exp2f_core(z));
-    v = v < 0x3f800000u ? v : 0x3f800000u;     // min(v, 1.0f) on the encodings: v is a positive finite float whenever it is used
-    return (x >= RD_FLT_MIN) ? rd_u2f(v) : 0.0f;
+    const float v = rd_exp2f_core_clamp01(z);  // min(2^z, 1): v is a positive finite float whenever it is used
+    return (x >= RD_FLT_MIN) ? v : 0.0f;
 }
