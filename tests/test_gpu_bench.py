@@ -97,8 +97,11 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     for k in ("pinned_dst", "pageable_dst_reused", "pageable_dst_fresh", "borrowed_surface"):
         assert fr[k]["ms"] > 0 and fr[k]["GBps_over_pcie"] > 0 and fr[k]["limiter"]
     assert fr["pinned_dst"]["ms"] <= 2.5 and fr["borrowed_surface"]["ms"] <= 2.5, fr    # the bar: a 24 MP export costs the PCIe transfer
-    for k in ("rgb8", "rgba8"):
+    for k in ("rgb8", "rgba8", "rgb8_from_pinned_host", "rgb8_from_pageable_host"):     # (the last two: rd_exporter_submit_host)
         assert ex["export_ring"][k]["verified"] is True and ex["export_ring"][k]["ms_per_frame"] > 0
+    # the narrow surfaces carry the VALU roofline of their threshold-table kernels (round 4: no transcendental left in either)
+    assert ex["batch_rgba8"]["roofline"]["bound"] == "valu" and ex["batch_rgba8"]["roofline"]["valu_issue_cycles_per_tile"] == 698
+    assert ex["config5_shape_f16"]["roofline"]["bound"] == "valu" and ex["config5_shape_f16"]["roofline"]["valu_issue_cycles_per_tile"] == 876
     # the box's own ceilings, measured in this run (item 4)
     rf = r["roofline"]
     assert rf["box_copy_GBps"] > 3000 and rf["box_fill_GBps"] > 3000 and 0 < rf["frac_of_box_copy"] < 1.2
