@@ -341,6 +341,15 @@ struct rd_quads_call {
     }
 };
 
+// How the export kernel tiles a row of W pixels (W even; rd_kernels.h, TILES).  RD_TILES=overlap (A/B switch) runs the
+// pulled-back-last-tile instance on widths that need none.
+static int rd_tiles_mode(uint32_t W)
+{
+    static const bool force_overlap = getenv("RD_TILES") && !strcmp(getenv("RD_TILES"), "overlap");
+    if (W < 128u) return RD_TILES_MASKED;
+    return (W % 128u == 0 && !force_overlap) ? RD_TILES_WHOLE : RD_TILES_OVERLAP;
+}
+
 template <int FMT, bool HIST, int MATH>
 static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32_t H, uint32_t unit0,
                               uint32_t unit1, uint32_t blocks, const rd_ku &u_in, uint32_t *slab32,
@@ -367,9 +376,15 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && (burst_env < 0 || burst_env != 0);
     c.blocks = blocks; c.cfa = cfa; c.out = out; c.W = W; c.H = H; c.unit0 = unit0; c.unit1 = unit1; c.tq = tq;
     c.slab32 = slab32; c.slab64 = slab64;
-    c.fn = W % 128u == 0 ? (const void *)rd_develop_quads<FMT, HIST, true, MATH, false> : (const void *)rd_develop_quads<FMT, HIST, false, MATH, false>;
+    // whole tiles for every even width from 128 up: a width that is not a multiple of 128 overlaps its last tile
+    // (rd_kernels.h, TILES); the masked instance is left for frames narrower than one tile
+    const int tiles = rd_tiles_mode(W);
+    c.fn = tiles == RD_TILES_WHOLE ? (const void *)rd_develop_quads<FMT, HIST, RD_TILES_WHOLE, MATH, false>
+         : tiles == RD_TILES_OVERLAP ? (const void *)rd_develop_quads<FMT, HIST, RD_TILES_OVERLAP, MATH, false>
+                                     : (const void *)rd_develop_quads<FMT, HIST, RD_TILES_MASKED, MATH, false>;
     if constexpr (FMT == RD_FMT_RGBA_F32) {     // the burst variant exists for the f32 surface only
-        if (W % 128u == 0 && burst) c.fn = (const void *)rd_develop_quads<FMT, HIST, true, MATH, true>;
+        if (burst && tiles == RD_TILES_WHOLE) c.fn = (const void *)rd_develop_quads<FMT, HIST, RD_TILES_WHOLE, MATH, true>;
+        if (burst && tiles == RD_TILES_OVERLAP) c.fn = (const void *)rd_develop_quads<FMT, HIST, RD_TILES_OVERLAP, MATH, true>;
     }
     c.bind();
     if (!record) (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
@@ -391,21 +406,23 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
     const uint32_t ndyn = ntiles > nwaves ? ntiles - nwaves : 0u;
     const uint32_t tq_tmax = tq_k ? (ndyn + tq_k - 1u) / tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;
-    const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && W % 128u == 0 && (uint64_t)(H / 2u + 1u) * W >= (1u << 19) &&
+    const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && W >= 128u && (uint64_t)(H / 2u + 1u) * W >= (1u << 19) &&
                        (burst_env < 0 || burst_env != 0);
+    const int tiles = rd_tiles_mode(W);
+#define RD_LAUNCH_BATCH(TILES, BURST)                                                                                        \
+    hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, TILES, MATH, BURST>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes, \
+                       W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64)
     if constexpr (FMT == RD_FMT_RGBA_F32) {
         if (burst) {
-            hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, true, MATH, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes,
-                               W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64);
+            if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, true);
+            else RD_LAUNCH_BATCH(RD_TILES_OVERLAP, true);
             return;
         }
     }
-    if (W % 128u == 0)
-        hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, true, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes,
-                           W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64);
-    else
-        hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, false, MATH, false>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes,
-                           W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64);
+    if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
+    else if (tiles == RD_TILES_OVERLAP) RD_LAUNCH_BATCH(RD_TILES_OVERLAP, false);
+    else RD_LAUNCH_BATCH(RD_TILES_MASKED, false);
+#undef RD_LAUNCH_BATCH
 }
 
 template <int FMT, bool HIST, int MATH>

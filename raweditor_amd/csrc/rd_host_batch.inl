@@ -47,7 +47,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
     if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs width %% 128 == 0 (got %u)", w);
+    if (fmt == RD_FMT_RGB_U8 && w < 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs a frame at least 128 pixels wide (got %u)", w);
     const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
     if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
     int n_cu = 0;
@@ -640,7 +640,7 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
     if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "export needs an even frame width (got %u)", w);
     const size_t bpp = rd_format_bytes_per_pixel(fmt);
     if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
-    if (fmt == RD_FMT_RGB_U8 && w % 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 export needs width %% 128 == 0 (got %u)", w);
+    if (fmt == RD_FMT_RGB_U8 && w < 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 export needs a frame at least 128 pixels wide (got %u)", w);
     if (math_mode != RD_MATH_STRICT && math_mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", math_mode);
     if (!(rd_identity_map(w) && rd_identity_map(h))) return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h);
     int n_cu = 0;

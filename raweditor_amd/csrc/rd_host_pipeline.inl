@@ -299,7 +299,7 @@ static bool rd_pipeline_uses_quads(const rd_pipeline *p, const rd_shot &sh, uint
 {
     const uint32_t W = p->info.width, H = p->info.height;
     return tw == W && th == H && sh.export_view && (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
-           (fmt != RD_FMT_RGB_U8 || W % 128u == 0) && !getenv("RD_FORCE_MAP");
+           (fmt != RD_FMT_RGB_U8 || W >= 128u) && !getenv("RD_FORCE_MAP");     // (RGB8 narrower than one tile: the map kernel's byte stores)
 }
 
 // Enqueue one render of the snapshot on stream s: units [unit0, unit1) of the export kernel (the whole frame is

@@ -811,8 +811,17 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 #define RD_COLOUR rd_colour_m<MATH>
 #endif
 
-// FULL = every tile is a whole 64 quads (W % 128 == 0, true for 6016 and 11648): no lane masks, so
-// every vector-memory instruction of the loop body is issued unconditionally.  That matters: vmcnt
+// TILES says how a unit's 64-quad tiles cover its W/2 quads:
+//   RD_TILES_WHOLE    W % 128 == 0 (6016, 11648): the tiles abut;
+//   RD_TILES_OVERLAP  any other even W >= 128 (round 5; the frames cameras make are 6000, 8256, 5472, 7360 ... wide and
+//                     shaders.rs:181-187 renders any size): the LAST tile of a unit starts at quad W/2 - 64 instead of
+//                     64 * (tiles - 1), i.e. it overlaps its predecessor by 64 - (W/2) % 64 quads, recomputes them and stores
+//                     the same bytes a second time; only the histogram must not count those lanes twice, and an LDS atomic
+//                     may sit behind a lane mask (it is not vector memory).  Costs 8-22 issue cycles per tile
+//                     (tools/isa_budget.py), which is why the abutting case keeps its own instance;
+//   RD_TILES_MASKED   W < 128: one partial tile per unit, lane masks everywhere.
+// FULL (= not MASKED) = every tile is a whole 64 quads: no lane masks, so every vector-memory instruction of the loop body
+// is issued unconditionally.  Why that matters: vmcnt
 // retires in issue order, and hipcc can only leave the four stores of tile i in flight while it
 // waits for the prefetched loads of tile i+1 (s_waitcnt vmcnt(4)) if it can COUNT them; one store
 // behind a branch makes it fall back to vmcnt(0), which drains the store queue every iteration
@@ -822,6 +831,9 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // One tile's results, packed the way its surface stores want them, carried in registers from the
 // iteration that computes them to the next one, which stores them (f16 / u8 / rgb8; the f32 tile waits
 // in the LDS stage).
+#define RD_TILES_MASKED 0
+#define RD_TILES_WHOLE 1
+#define RD_TILES_OVERLAP 2
 template <int FMT> struct rd_tile_out;
 template <> struct rd_tile_out<RD_FMT_RGBA_F32> { };      // nothing: the f32 tile waits in the wave's LDS stage, not in registers
 template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
@@ -850,7 +862,7 @@ static_assert(sizeof(rd_frame_desc) == 192, "rd_frame_desc is three 64-byte line
 //                computed while the previous frame's last ones are still being stored.  A wave re-reads the
 //                uniforms (scalar loads, ~190 B) only when its compute stage changes frame: about once per
 //                (tiles per frame / resident waves) = 11 tiles at 24 MP.
-template <int FMT, bool HIST, bool FULL, int MATH, bool BURST, bool MULTI>
+template <int FMT, bool HIST, int TILES, int MATH, bool BURST, bool MULTI>
 __device__ __forceinline__ void
 rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, uint32_t W, uint32_t H, uint32_t unit0,
               uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
@@ -862,6 +874,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     // keeps the compiler from folding them back into scalar operands -- which leaves every instance at <= 78 SGPRs / <= 63 VGPRs
     // (raweditor_amd/kernel_resources.json; the build fails beyond the budget).  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
     // that is not what limits this kernel: DESIGN.md section 6.)
+    constexpr bool FULL = TILES != RD_TILES_MASKED;
     rd_ku u;
     auto adopt = [&](const rd_ku &src_mem) {                     // take over one frame's uniforms (MULTI: on every frame change)
         rd_ku src = src_mem;
@@ -921,6 +934,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qpr = W >> 1;                                 // quads per unit
+    // first quad of tile pq of a unit (wave-uniform, SALU): tiles abut, except that RD_TILES_OVERLAP pulls the last one back
+    // to end at the row's end
+    auto qbase = [&](uint32_t pq) -> uint32_t {
+        const uint32_t b = pq * 64u;
+        if constexpr (TILES == RD_TILES_OVERLAP) { const uint32_t last = qpr - 64u; return b < last ? b : last; }
+        else return b;
+    };
     const uint32_t ntiles = MULTI ? nframes * tpf : (unit1 - unit0) * tpu;   // < 2^32: checked on the host
     const uint32_t nwaves = gridDim.x * RD_WAVES;
     const uint32_t copy = lane & (RD_HK - 1);
@@ -990,8 +1010,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         if constexpr (FULL) {
             // wave-uniform base (SALU, 64-bit) + the lane's own dword: global_load_dword v_lane4, s[base] -- no per-tile
             // 64-bit VALU address arithmetic (it was 14 issue cycles per tile, tools/isa_budget.py)
-            top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)ra * W + (size_t)pq * 128u))[lane];
-            bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)rb * W + (size_t)pq * 128u))[lane];
+            const size_t x0 = (size_t)qbase(pq) * 2u;
+            top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)ra * W + x0))[lane];
+            bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)rb * W + x0))[lane];
         } else {
             uint32_t q = pq * 64u + lane;
             q = q < qpr ? q : qpr - 1u;                          // clamp: loaded but never used
@@ -1003,7 +1024,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     // demosaic + colour stack + histogram of one tile -> packed results
     auto compute_tile = [&](uint32_t tu, uint32_t tq, uint32_t top, uint32_t bot) {
         const bool has_a = tu != 0u, has_b = 2u * tu < H;        // wave-uniform
-        const bool valid = FULL || (tq * 64u + lane) < qpr;
+        // lanes that count in the histogram: all (WHOLE); all but the quads a pulled-back last tile shares with its
+        // predecessor (OVERLAP: tq * 64 - qbase(tq) of them, 0 for every other tile); the lanes inside the row (MASKED)
+        const bool valid = TILES == RD_TILES_WHOLE || (TILES == RD_TILES_OVERLAP ? lane >= tq * 64u - qbase(tq) : (tq * 64u + lane) < qpr);
         float A, B, C, D;
 #ifdef RD_BUDGET_ELIDE                                           // tools/isa_budget.py: one path in the assembly
         constexpr bool black0 = true;
@@ -1214,8 +1237,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         const bool has_a = tu != 0u, has_b = 2u * tu < H;
         const size_t row_b_px = (size_t)(has_b ? 2u * tu : 2u * tu - 1u) * W;
         const size_t row_a_px = has_a ? (size_t)(2u * tu - 1u) * W : row_b_px;
-        const uint32_t q = tq * 64u + lane;
-        const bool valid = FULL || q < qpr;
+        const uint32_t q0 = qbase(tq);                           // the tile's first quad
+        const bool valid = FULL || q0 + lane < qpr;
         if constexpr (FMT == RD_FMT_RGBA_F32) {
             (void)r;
             const rd_f4 *st = stage + (size_t)wave * 192u;       // written by compute_tile
@@ -1224,7 +1247,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 #pragma unroll
             for (uint32_t half = 0; half < 2u; ++half) {
                 const uint32_t p = half * 64u + lane;                  // pixel within the tile
-                const uint32_t px = tq * 128u + p;                     // column
+                const uint32_t px = q0 * 2u + p;                       // column
                 const uint32_t ja = (p >> 1) * 3u;                     // row a: c1 of quad p/2
                 const uint32_t jb = ja + 1u + (p & 1u);                // row b: c2 (even col) / c3 (odd col)
                 const rd_f4 va = st[has_a ? ja : jb];                  // a missing row re-stores the other one: the select is
@@ -1248,14 +1271,16 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
             }
             if (valid) {                                         // wave-uniform base + the lane's own 16 bytes (see load_tile)
-                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)tq * 64u) + lane);
-                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)tq * 64u) + lane);
+                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)q0) + lane);
+                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)q0) + lane);
             }
         } else if constexpr (FMT == RD_FMT_RGB_U8) {
             // 2 px = 6 B per lane per row: repack the wave's 384-B rows through LDS (three 16-bit writes per
             // lane and row) and store whole dwords: lane l stores dword l, lanes 0..31 also dword 64+l.
-            // Full tiles only (the host routes other widths to rd_develop_map): W % 128 == 0 makes every
-            // row start and tile start a multiple of 4 bytes.
+            // Full tiles only (the host routes W < 128 to rd_develop_map).  A row (3 W bytes) and a tile (6 q0 bytes) start on
+            // an EVEN byte, a multiple of 4 only when W % 4 == 0 and q0 is even: the dword stores are declared 2-byte
+            // aligned (rd_u32_a2) -- gfx950 under HSA runs with unaligned global access enabled, hipcc keeps them
+            // global_store_dword, and the oracle tests at W = 6002 / 130 / 202 exercise the odd case.
             uint16_t *s16 = rgb16 + (size_t)wave * 384u;
             uint32_t pa = r.v1, pb = r.v1, pc = r.v2, pd = r.v3;       // row a: (c1,c1)  row b: (c2,c3)
             if (!has_a) { pa = pc; pb = pd; }
@@ -1268,8 +1293,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             s16[192u + lane * 3u + 2u] = (uint16_t)(pd >> 8);
             __builtin_amdgcn_wave_barrier();
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s16);
-            RD_GLOBAL uint32_t *oa = reinterpret_cast<RD_GLOBAL uint32_t *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_a_px + (size_t)tq * 128u) * 3u);
-            RD_GLOBAL uint32_t *ob = reinterpret_cast<RD_GLOBAL uint32_t *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_b_px + (size_t)tq * 128u) * 3u);
+            typedef uint32_t rd_u32_a2 __attribute__((aligned(2)));
+            RD_GLOBAL rd_u32_a2 *oa = reinterpret_cast<RD_GLOBAL rd_u32_a2 *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_a_px + (size_t)q0 * 2u) * 3u);
+            RD_GLOBAL rd_u32_a2 *ob = reinterpret_cast<RD_GLOBAL rd_u32_a2 *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_b_px + (size_t)q0 * 2u) * 3u);
             const uint32_t a0 = s32[lane], b0 = s32[96u + lane];
             const uint32_t l2 = lane & 31u;
             const uint32_t a1 = s32[64u + l2], b1 = s32[160u + l2];
@@ -1288,8 +1314,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(vb.x), "+v"(vb.y));
             }
             if (valid) {
-                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)tq * 64u) + lane);
-                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)tq * 64u) + lane);
+                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)q0) + lane);
+                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)q0) + lane);
             }
         }
     };
@@ -1315,10 +1341,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             const uint32_t row_lo = MULTI ? 0u : unit0 ? 2u * unit0 - 1u : 0u;
             const uint32_t row_hi = MULTI ? H : 2u * (unit1 - 1u) < H ? 2u * (unit1 - 1u) + 1u : H;    // exclusive
             const RD_GLOBAL uint16_t *cfa_b = (const RD_GLOBAL uint16_t *)(MULTI ? descs[0].cfa : cfa_arg);
-            const RD_GLOBAL rd_u4 *src = reinterpret_cast<const RD_GLOBAL rd_u4 *>(cfa_b + (size_t)row_lo * W);
-            const size_t n16 = ((size_t)(row_hi - row_lo) * W * sizeof(uint16_t)) / 16u;       // whole 16-B chunks
+            // (rows of a width that is not a multiple of 8 start off a 16-byte boundary: the sweep starts at the boundary below
+            // the band's first row -- still inside the plane -- and covers whole 16-B chunks up to the band's end)
+            const size_t b_lo = ((size_t)row_lo * W * sizeof(uint16_t)) & ~(size_t)15u;
+            const RD_GLOBAL rd_u4 *src = reinterpret_cast<const RD_GLOBAL rd_u4 *>(reinterpret_cast<const RD_GLOBAL char *>(cfa_b) + b_lo);
+            const size_t n16 = ((size_t)row_hi * W * sizeof(uint16_t) - b_lo) / 16u;
             const size_t g0 = (size_t)(blockIdx.x * RD_WAVES + wave) * 64u, gstride = (size_t)nwaves * 64u;
-            // (host guarantees for BURST launches: cfa 16-byte aligned, W % 128 == 0, at least 1 MB of CFA rows,
+            // (host guarantees for BURST launches: cfa 16-byte aligned, W even and >= 128, at least 1 MB of CFA rows,
             //  so src is aligned, n16 >= 64 and every instruction below is unconditional)
             {                                                    // launches > 64 MB only: the part beyond 8 x 1 KiB per wave
                 uint32_t sink = 0;
@@ -1334,7 +1363,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             // loads are the oldest of ten outstanding operations, so vmcnt(8) is exactly "they have landed".
             // Nothing else is in flight here (first memory instructions of the wave after the waited loop).
             {
-                uint32_t q = qt * 64u + lane;
+                uint32_t q = qbase(qt) + lane;
                 const uint32_t ra = unit ? 2u * unit - 1u : 0u;
                 const uint32_t rb = 2u * unit < H ? 2u * unit : H - 1u;
                 const RD_GLOBAL uint32_t *pt = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W) + q;
@@ -1471,26 +1500,26 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 
 // One frame, or one row band of a frame, per launch: rd_render*, the export ring, and rd_batch_develop when the
 // multi-frame launch is switched off (RD_BATCH_PERSISTENT=0).
-template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
+template <int FMT, bool HIST, int TILES, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
 __global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                  uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k,
                  uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
 {
-    rd_quads_body<FMT, HIST, FULL, MATH, BURST, false>(cfa, out, W, H, unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u_arg,
+    rd_quads_body<FMT, HIST, TILES, MATH, BURST, false>(cfa, out, W, H, unit0, unit1, tpu, tpu_magic, tq_k, tq_tmax, tq, u_arg,
                                                        slab32, slab64, nullptr, 1u, 0u, 0u);
 }
 
 // `nframes` whole frames of one size per launch (descs[0 .. nframes-1], frame-major tile index; tpf = tiles per
 // frame): the batch path.  Histogram counts of all frames meet in the workgroup's LDS table (u32: the host keeps
 // nframes * W * H below 2^32) and are added to its u64 slab row at the end of the launch.
-template <int FMT, bool HIST, bool FULL, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
+template <int FMT, bool HIST, int TILES, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
 __global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
 rd_develop_batch(const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t W, uint32_t H, uint32_t tpu,
                  uint32_t tpu_magic, uint32_t tpf, uint32_t tpf_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
                  unsigned long long *slab64)
 {
-    rd_quads_body<FMT, HIST, FULL, MATH, BURST, true>(nullptr, nullptr, W, H, 0u, H / 2u + 1u, tpu, tpu_magic, tq_k, tq_tmax, tq,
+    rd_quads_body<FMT, HIST, TILES, MATH, BURST, true>(nullptr, nullptr, W, H, 0u, H / 2u + 1u, tpu, tpu_magic, tq_k, tq_tmax, tq,
                                                       descs[0].u, nullptr, slab64, descs, nframes, tpf, tpf_magic);
 }
 

@@ -136,7 +136,10 @@ def check_batch(rng):
     n = int(rng.integers(1, 13))
     math = int(rng.integers(0, 2))
     fmt, dtype, ch, pack = [(ra.FMT_RGBA_F32, np.float32, 4, None), (ra.FMT_RGBA_U8, np.uint8, 4, refc.pack_u8),
-                            (ra.FMT_RGBA_F16, np.uint16, 4, refc.pack_f16)][rng.integers(0, 3)]
+                            (ra.FMT_RGBA_F16, np.uint16, 4, refc.pack_f16),
+                            (ra.FMT_RGB_U8, np.uint8, 3, lambda e: np.ascontiguousarray(refc.pack_u8(e)[..., :3]))][rng.integers(0, 4)]
+    if fmt == ra.FMT_RGB_U8 and w < 128:                          # the RGB8 batch needs one whole tile per row
+        fmt, dtype, ch, pack = ra.FMT_RGBA_U8, np.uint8, 4, refc.pack_u8
     bands = int(rng.integers(1, 4))
     cap = rng.choice(("", "1", "2", "3", "8"))
     cases = []

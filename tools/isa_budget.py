@@ -148,8 +148,11 @@ def extract_function(asm_lines, mangled_prefix):
 
 
 def mangle(template_args):
-    """'<2,true,true,0,false>' -> _Z16rd_develop_batchILi2ELb1ELb1ELi0ELb0EE"""
+    """'<2,true,1,0,false>' -> _Z16rd_develop_batchILi2ELb1ELi1ELi0ELb0EE  (FMT, HIST, TILES, MATH, BURST; the round-4
+    spelling '<2,true,true,0,false>' -- TILES was a bool then -- still names the abutting-tiles instance)"""
     parts = [p.strip() for p in template_args.strip("<>").split(",")]
+    if len(parts) > 2 and parts[2] in ("true", "false"):
+        parts[2] = "1" if parts[2] == "true" else "0"
     out = "_Z16rd_develop_batchI"
     for p in parts:
         if p in ("true", "false"):
@@ -161,7 +164,7 @@ def mangle(template_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="<2,true,true,0,false>", help="template arguments of rd_develop_batch<FMT,HIST,FULL,MATH,BURST>")
+    ap.add_argument("--kernel", default="<2,true,true,0,false>", help="template arguments of rd_develop_batch<FMT,HIST,TILES,MATH,BURST> (TILES: 0 masked, 1 whole, 2 overlapped last tile)")
     ap.add_argument("--asm", help="an existing -gline-tables-only -S output (skips the compile)")
     ap.add_argument("--listing", help="write the annotated main-loop listing here")
     ap.add_argument("--summary", help="write the per-stage table here (also printed)")

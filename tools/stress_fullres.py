@@ -103,8 +103,6 @@ def one_call(rng, fr, scratch):
         return "render f16 + hist", (np.array_equal(got.view(np.uint16), e["f16"].view(np.uint16))
                                      and np.array_equal(hist, e["hist"]))
     if k == 9:
-        if w % 128:
-            return "render rgb8 (skipped)", True
         return "render rgb8", np.array_equal(p.render(fmt=ra.FMT_RGB_U8), e["u8"][..., :3])
     if k == 10:
         return "calculate_histogram(full)", np.array_equal(p.calculate_histogram(e["u8"]), e["hist"])
