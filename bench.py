@@ -44,7 +44,7 @@ WB = (2.0, 1.0, 1.5, 1.0)
 CM = (1.6, -0.4, -0.2, -0.3, 1.5, -0.2, 0.0, -0.5, 1.5)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HBM_COPY_GBPS = 6290.0           # MI355X_MICROARCH.md: what a streaming copy reaches on this part ("~6.3 TB/s achievable")
-BYTES_PER_PX = {"f32": 18, "f16": 10, "u8": 6}   # 2 B CFA read + surface write
+BYTES_PER_PX = {"f32": 18, "f16": 10, "u8": 6, "rgb8": 5}   # 2 B CFA read + surface write
 
 
 def parse_args(argv=None):
@@ -406,10 +406,26 @@ def valu_fields(fmt_name, W, H, us_per_frame, valu_ns, n_simd=1024):
 
 
 def bound_of(fmt_name, hbm_frac, valu):
-    """Which roofline binds: the narrow surfaces are VALU-issue-bound (their HBM traffic is ~1.0x algorithmic and they speed
-    up with fewer instructions, not with fewer bytes): "valu", as VERDICT round 3 asked; the f32 surface -- the headline -- is
-    HBM-bound with the VALU co-critical on boxes that clock low (valu_issue_frac beside it says how close)."""
+    """`roofline.bound` as DECLARED: the roofline this surface has been found on over four rounds of A/B runs -- the narrow
+    surfaces are VALU-issue-bound (their HBM traffic is ~1.0x algorithmic and they speed up with fewer instructions, not with
+    fewer bytes): "valu", as VERDICT round 3 asked; the f32 surface -- the headline, whose achieved / peak are HBM figures -- is
+    "hbm".  What THIS run's two fractions say is `bound_measured` (bound_measured_of below)."""
     return "hbm" if fmt_name == "f32" else "valu"
+
+
+def bound_measured_of(achieved_GBps, box_copy_GBps, valu):
+    """Derived from the run, not declared: the HBM fraction against what this box's memory system delivers (its measured copy
+    rate; the guide's 6290 GB/s when the run has no probe) beside the VALU issue fraction.  The larger one names the bound;
+    within 5 % of each other both do."""
+    ceiling = box_copy_GBps or HBM_COPY_GBPS
+    h = achieved_GBps / ceiling
+    v = (valu or {}).get("valu_issue_frac")
+    if v is None:
+        return {"bound_measured": None, "bound_measured_note": "no VALU figure in this run"}
+    which = "hbm+valu" if abs(h - v) <= 0.05 else ("hbm" if h > v else "valu")
+    return {"bound_measured": which,
+            "bound_measured_note": f"hbm {h:.3f} of {'this box copy rate' if box_copy_GBps else 'the guide copy figure'} "
+                                   f"({ceiling:.0f} GB/s) vs valu issue {v:.3f}; `bound` is the declared roofline"}
 
 
 def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform"):
@@ -488,6 +504,7 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
         "roofline": {
             "bound": bound_of(args.format, achieved / HBM_PEAK_GBPS, valu), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, **valu,
+            **bound_measured_of(achieved, box.get("copy"), valu),
             "traffic_source": traffic_source,
             "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBPS, 4),      # reported beside `frac`, never instead of it
             # this box, this run, before the headline (rd_measure_hbm: float4 copy / nt fill / read of 1 GiB, median of 5)
@@ -516,6 +533,7 @@ def roofline_of(fmt_name, W, H, us_per_frame, mode, kernel, valu_ns=None):
     valu = valu_fields(fmt_name, W, H, us_per_frame, valu_ns) if kernel == "rd_develop_batch" else {}
     return {"bound": bound_of(fmt_name, ach / HBM_PEAK_GBPS, valu) if valu else ("hbm" if fmt_name == "f32" else "valu"),
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), **valu,
+            **(bound_measured_of(ach, None, valu) if valu else {}),
             "traffic": int(per_frame) if per_frame is not None else None, "traffic_source": src,
             "traffic_unit": "HBM bytes per frame", "kernel": kernel, "algorithmic_bytes_per_frame": alg}
 
@@ -572,7 +590,7 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     """A batch workload on another surface format / frame size, timed like the headline (HIP events, descriptors alternate).
     tiled: RD_BATCH_PERSISTENT=0 for this context -- every frame is `row_bands` separate row-band launches (BASELINE
     config 5's "tiled multi-launch per frame"); by default the multi-frame launch needs no bands of its own and ignores them."""
-    fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8}[fmt_name]
+    fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8, "rgb8": ra.FMT_RGB_U8}[fmt_name]
     bpp = ra.BYTES_PER_PIXEL[fmt]
     F = len(cfas)
     ring = [torch.empty(H * W * bpp, dtype=torch.uint8, device=dev) for _ in range(ring_n)]
@@ -727,11 +745,13 @@ def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
         ex.close()
     # The same ring fed from HOST memory (rd_exporter_submit_host: the decoded files of a folder export, raw/loader.rs:11-19):
     # upload of frame i+1, kernel of frame i+1 and read-back of frame i overlap; page-locked planes and pageable ones.
+    pins, ex = [], None
     try:
         ex = ra.Exporter(dev_index, W, H, ra.FMT_RGB_U8, n_slots=2)
         k = min(4, len(cfas))
         host = [np.ascontiguousarray(cfas[i].cpu().numpy()).view(np.uint16) for i in range(k)]
-        pins = [ra.PinnedBytes(W * H * 2) for _ in range(k)]
+        for _ in range(k):
+            pins.append(ra.PinnedBytes(W * H * 2, device=dev_index))
         for pin, a in zip(pins, host):
             pin.array.view(np.uint16)[:] = a.reshape(-1)
         for name, planes in (("rgb8_from_pinned_host", [pin.array.view(np.uint16) for pin in pins]), ("rgb8_from_pageable_host", host)):
@@ -750,15 +770,51 @@ def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
             out[name] = {"ms_per_frame": round(dt / n * 1e3, 3), "frames_per_s": round(n / dt, 1),
                          "GBps_up_plus_down": round(n * (W * H * 2 + W * H * 3) / dt / 1e9, 1), "frames": n, "slots": 2,
                          "verified": bool(ok), "verified_note": f"{info} row bands of the last frame bit-identical to the oracle" if ok else str(info)}
-        ex.close()
-        for pin in pins:
-            pin.free()
     except Exception as exc:                                      # an extra must not cost the line
         out["rgb8_from_host_error"] = f"{type(exc).__name__}: {exc}"
+    finally:                                                      # on every path: the ring, then the page-locked planes it read
+        if ex is not None:
+            ex.close()
+        for pin in pins:
+            pin.free()
     out["config"] = (f"export ring (rd_exporter_*): {n_frames} x {W}x{H} frames resident in HBM -> fused develop -> pinned host ring, "
                      "PCIe-inclusive; RGB8 = JPEG feed (alpha strip fused), RGBA8 = PNG feed; *_from_*_host: the CFA planes "
                      "start in host memory too (48 MB up + 72 MB down per frame)")
     return out
+
+def extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None):
+    """A frame width that is not a multiple of the export kernel's 128-pixel tile -- 6000 x 4000, what most 24 MP cameras
+    make (the reference renders any size, shaders.rs:181-187) -- beside 6016 x 4016: the same 64-frame batch per surface,
+    the two sizes alternating three times on this box, best of each; `ns_per_px_ratio` = ragged / aligned time per PIXEL."""
+    Wr, Hr = 6000, 4000
+    nf = min(64, len(cfas))
+    cr, pr = make_batch(torch, np, ra, dev, Wr, Hr, nf, 1 << 21, 1)
+    ca, pa = cfas[:nf], params[:nf]
+    out = {"config": f"{nf} x {Wr}x{Hr} (W % 128 = {Wr % 128}: every row pair ends in a pulled-back, overlapping tile; RGBA8 / RGB8 rows are "
+                     f"{Wr * 4} / {Wr * 3} bytes, not whole 128-byte lines) beside {nf} x 6016x4016, randomised stacks, fused histogram, "
+                     "strict f32 arithmetic, multi-frame launches"}
+    worst = 0.0
+    for fmt_name in ("f32", "f16", "u8", "rgb8"):
+        ring = 8 if fmt_name == "f32" else 16
+        best = {}
+        for rep in range(3):
+            for tag, (cc, pp, W, H) in (("aligned", (ca, pa, 6016, 4016)), ("ragged", (cr, pr, Wr, Hr))):
+                r = extra_batch(torch, np, ra, dev, dev_index, fmt_name, cc, pp, W, H, ring, 1, 8, stream, f"{fmt_name} {W}x{H}", "multi",
+                                valu_ns=valu_ns)
+                if tag not in best or r["us_per_frame"] < best[tag]["us_per_frame"]:
+                    best[tag] = r
+        a, b = best["aligned"], best["ragged"]
+        ratio = (b["us_per_frame"] / (Wr * Hr)) / (a["us_per_frame"] / (6016 * 4016))
+        worst = max(worst, ratio)
+        out[fmt_name] = {"aligned_us_per_frame": a["us_per_frame"], "ragged_us_per_frame": b["us_per_frame"],
+                         "aligned_MP_per_s": a["MP_per_s"], "ragged_MP_per_s": b["MP_per_s"], "ns_per_px_ratio": round(ratio, 4),
+                         "ragged_hbm_frac": b["roofline"]["frac"], "verified": bool(a["verified"] and b["verified"]),
+                         "verified_note": b["verified_note"]}
+    out["worst_ns_per_px_ratio"] = round(worst, 4)
+    out["verified"] = all(out[f]["verified"] for f in ("f32", "f16", "u8", "rgb8"))
+    del cr
+    return out
+
 
 def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None):
     out = {}
@@ -781,6 +837,7 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
                                                  "the same 16 x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
                                                  "8 row-band launches per frame (RD_BATCH_PERSISTENT=0)", "per_frame", tiled=True)
     del c5
+    out["ragged_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 
@@ -1037,13 +1094,19 @@ def run_node(args):
     nstep = [0]
     hist = None
 
+    drain = os.environ.get("RD_NODE_HIST_SYNC", "") == "1"   # A/B: rounds 2-4's step (histogram() synchronises every step)
+
     def step():
         nonlocal hist
         nb.develop(arrays[nstep[0] % len(arrays)], row_bands=args.row_bands)
         nstep[0] += 1
         if with_hist:
-            hist = nb.histogram()                          # per-device fold + all-reduce + read-back; synchronises
-        # without a histogram the steps queue up on the devices' streams; the region ends with nb.synchronize()
+            # per-device fold + all-reduce + read-back, ENQUEUED (round 5): like the one-process-per-GPU host, whose fold and
+            # all-reduce are stream-ordered, the steps queue up on the devices' streams; the last result is fetched after the region
+            if drain:
+                hist = nb.histogram()
+            else:
+                nb.histogram_enqueue()
 
     for _ in range(args.warmup):
         step()
@@ -1062,6 +1125,8 @@ def run_node(args):
         nb.synchronize()
         elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                         # HIP events on device 0's launch stream
+    if with_hist and not drain:
+        hist = nb.histogram_fetch()                        # the last step's global histogram (its read-back landed before the synchronise)
 
     if with_hist:
         got = int(hist.sum())
@@ -1077,14 +1142,14 @@ def run_node(args):
     dup = len(set(devices)) < N
     result = result_line(args, N, F, W, H, elapsed, dev_ms, lpc, len(per_dev[0][2]), verified, verified_note,
                          f"ONE process, rd_node_batch_* over devices {devices} (one rd_batch + stream + host thread per device); "
-                         f"histogram reduction: {nb.reduce_kind()}; each step = develop + histogram (synchronises)" +
+                         f"histogram reduction: {nb.reduce_kind()}; each step = develop + histogram " + ("(synchronises)" if drain else "fold / all-reduce / read-back enqueued (no drain between steps)") +
                          ("; REHEARSAL: a device is listed more than once, the ranks share one GPU" if dup else ""),
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
                          "steps alternate between two frame arrays: every step uploads its descriptors", box=box)
     result["devices"] = [{"slot": i, "device_index": d, "pci_bus_id": idents[i].get("pci_bus_id"), "name": idents[i].get("name"),
                           "launches": nb.last_launch_count(i) * args.steps} for i, d in enumerate(devices)]
     result["distinct_devices"] = len({(i.get("pci_bus_id") or f"index:{d}") for i, d in zip(idents, devices)})
-    if with_hist:
+    if with_hist and drain:
         result["step_ms"] = {"min": round(min(step_ms), 4), "median": round(sorted(step_ms)[len(step_ms) // 2], 4), "max": round(max(step_ms), 4),
                              "all": [round(x, 3) for x in step_ms] if len(step_ms) <= 32 else None,
                              "note": "host wall time of each step (develop + histogram, which synchronises)"}

@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - every function returns an rd_status (0 = ok, negative = error) unless noted; the message of
- *     the last error on the calling thread is rd_last_error().  Nothing aborts or throws.
+ *     the last error on the calling thread is rd_last_error().  Nothing aborts or throws: no C++ exception leaves an
+ *     entry point (std::bad_alloc -> RD_ERR_OOM, anything else -> RD_ERR_INTERNAL; the handle stays valid).
  *   - host buffers are caller-owned and tightly packed (the reference strips wgpu's 256-byte row
  *     padding, pipeline.rs:511-521, :595-601); `*_len` arguments are byte lengths and are checked.
  *   - a pipeline handle may be used from several threads at once (the reference shares
@@ -35,16 +36,23 @@ extern "C" {
  * guards the uniforms) and a full-resolution render is band-pipelined (see rd_render_full_res_to_bytes); new entry points
  * rd_host_alloc / rd_host_free (page-locked render destinations), rd_measure_hbm (the box's own streaming ceilings),
  * rd_render_full_res_borrow / rd_surface_release (a lent page-locked surface), rd_measure_valu, rd_device_identity, rd_selftest_q8_lut (+ _codes), rd_q8_lut_table,
- * rd_exporter_submit_host (the export ring fed from host memory), rd_selftest_f16_lut (+ _values), rd_f16_lut_tables. */
-#define RD_ABI_VERSION 3
+ * rd_exporter_submit_host (the export ring fed from host memory), rd_selftest_f16_lut (+ _values), rd_f16_lut_tables.
+ * 4: no signature changed.  New status RD_ERR_INTERNAL: a C++ exception inside the library (a failed host allocation is
+ * RD_ERR_OOM) stops at the C boundary and comes back as a status -- every entry point is a function-try-block; new test hook
+ * rd_debug_inject_fault.  RGB8 export (rd_batch_create, rd_exporter_create, rd_render) takes any even width from 128 up,
+ * and every even width >= 128 runs the export kernel's whole-tile instances (it was W % 128 == 0).  rd_node_batch_* keeps
+ * one worker thread per device for the life of the handle instead of starting N threads per call; new entry points
+ * rd_node_batch_histogram_enqueue / _fetch (the global histogram without draining the devices). */
+#define RD_ABI_VERSION 4
 
 typedef enum rd_status {
     RD_OK = 0,
     RD_ERR_INVALID_ARG = -1,
     RD_ERR_NO_DEVICE = -2,
     RD_ERR_HIP = -3,
-    RD_ERR_OOM = -4,
-    RD_ERR_UNSUPPORTED = -5
+    RD_ERR_OOM = -4,         /* device memory, page-locked memory, or a host allocation (std::bad_alloc) */
+    RD_ERR_UNSUPPORTED = -5,
+    RD_ERR_INTERNAL = -6     /* a C++ exception other than bad_alloc was stopped at the C boundary; rd_last_error() has what() */
 } rd_status;
 
 /* Output surface formats.  U8 is what the reference renders (Rgba8Unorm, pipeline.rs:322, :454,
@@ -262,6 +270,12 @@ int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_fr
 /* Global histogram of everything developed since the last call: per-device fold, all-reduce, copy to `hist`
  * (R[256] G[256] B[256], u64).  Returns when every device has finished; resets the accumulators. */
 int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768]);
+/* The same in two halves, for a host that develops call after call and must not drain its devices in between (round 5):
+ * _enqueue puts the per-device fold, the all-reduce and the read-back (into a page-locked buffer the handle owns) on the
+ * devices' streams and returns at once; _fetch waits for those read-backs only -- not for develop calls enqueued after them --
+ * and hands out the sum.  One result may be outstanding: only the LAST enqueue's result is what fetch returns. */
+int rd_node_batch_histogram_enqueue(rd_node_batch *nb);
+int rd_node_batch_histogram_fetch(rd_node_batch *nb, uint64_t hist[768]);
 int rd_node_batch_synchronize(rd_node_batch *nb);
 /* Measurement aids (bench.py --host node): the hipStream_t devices[index]'s share is enqueued on (record events there),
  * the fused launches its share of the last develop call took, and how the histogram is reduced (0 = one device, no
@@ -352,7 +366,9 @@ int rd_host_free(int device, void *ptr);
  * a float4 copy of `bytes` to another buffer (GB/s counts the bytes read plus the bytes written), a non-temporal float4
  * fill and a float4 read of `bytes` (a wave walks its own contiguous range, eight 1-KiB accesses in flight: the fastest
  * shape tools/hbm_probe.hip finds) and hipMemsetAsync beside them; each launched `reps` times on a private stream, the
- * median launch reported.  Any output may be NULL.  Allocates 2 x bytes of device memory for the call. */
+ * median launch reported.  Any output may be NULL.  Allocates up to 2 x bytes of device memory for the call: `bytes` is
+ * rounded DOWN to a multiple of 512 MiB (one 8-KiB step for each of the copy grid's 65 536 waves; the kernels have no tail
+ * handling) and a size below 512 MiB is RD_ERR_INVALID_ARG. */
 int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
                    double *memset_GBps);
 /* Measurement aid (bench.py's valu_issue_frac): nanoseconds one full-rate VALU wave-instruction (v_mul_f32 / v_add_f32, all
@@ -379,6 +395,19 @@ int rd_debug_is_pinned_host(const void *ptr, size_t len);   /* 1: a render into 
 /* devices[index]'s own 768 x u64 histogram buffer as the last rd_node_batch_histogram left it (after an all-reduce every
  * device holds the global sum). */
 int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768]);
+/* Fault injection: proves that nothing thrown inside the library crosses this boundary.  Arms ONE fault: the (after + 1)-th
+ * passage through a fault point named `site` throws once, then the fault disarms itself.  Fault points: every entry point
+ * under its own name ("rd_batch_develop"), the real allocation / thread-start sites ("pipeline.lanes", "batch.descs",
+ * "node.share", "node.thread", "scratch.entry", "exporter.slots"), "*" = whichever comes first.  site NULL or kind 0 disarms.
+ * The same through the environment, read when the library is loaded: RD_FAULT_INJECT=site:kind[:after]. */
+typedef enum rd_fault_kind {
+    RD_FAULT_NONE = 0,
+    RD_FAULT_BAD_ALLOC = 1,     /* std::bad_alloc            -> RD_ERR_OOM */
+    RD_FAULT_THREAD_START = 2,  /* std::system_error(EAGAIN) -> RD_ERR_INTERNAL */
+    RD_FAULT_RUNTIME = 3,       /* std::runtime_error        -> RD_ERR_INTERNAL */
+    RD_FAULT_FOREIGN = 4        /* not a std::exception      -> RD_ERR_INTERNAL */
+} rd_fault_kind;
+int rd_debug_inject_fault(const char *site, uint32_t kind, uint32_t after);
 
 #ifdef __cplusplus
 }

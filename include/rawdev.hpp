@@ -51,23 +51,60 @@ struct EditParams : rd_edit_params {
     bool is_unedited() const { return *this == EditParams(); }           // edit.rs:115-117
     void reset() { *this = EditParams(); }                               // edit.rs:120-122
 
-    // to_json (edit.rs:105-107): {"exposure":0.0,...} in field order, shortest round-trip f32.
+    // The text serde_json writes for a finite f32: the `ryu` crate's format32.  Shortest decimal digits that round-trip
+    // (digits x 10^k, kk = number of digits + k), laid out as
+    //   0 <= k && kk <= 13 : digits, k zeros, ".0"      0 < kk <= 13 : point inside the digits
+    //   -6 < kk <= 0       : "0.", -kk zeros, digits     otherwise    : d[.ddd]e<exp> (no '+', no padding): 1e-7, 1.5e-7, 1e13
+    // with a sign for negatives including -0.0.
+    static std::string ryu_f32(float v)
+    {
+        if (v == 0.0f) return std::signbit(v) ? "-0.0" : "0.0";
+        const std::string sign = v < 0.0f ? "-" : "";
+        const float a = std::fabs(v);
+        std::string digits;
+        int e10 = 0;
+        for (int n = 1; n <= 9 && digits.empty(); ++n) {                 // the shortest n digits that give `a` back
+            char buf[48];
+            std::snprintf(buf, sizeof buf, "%.*e", n - 1, (double)a);     // correctly rounded to n digits: d.ddde[+-]xx
+            unsigned long long m = 0;
+            const char *p = buf;
+            for (; *p && *p != 'e'; ++p)
+                if (*p >= '0' && *p <= '9') m = m * 10 + (unsigned long long)(*p - '0');
+            const int e = std::atoi(p + 1);
+            // (the interval of decimals that read back as `a` is lopsided at powers of two: a neighbour of the correctly
+            //  rounded n-digit decimal can lie inside it when that one does not)
+            const long long tries[3] = { 0, -1, 1 };
+            for (long long d : tries) {
+                const long long mm = (long long)m + d;
+                if (mm <= 0) continue;
+                char cand[64];
+                std::snprintf(cand, sizeof cand, "%llde%d", mm, e - (n - 1));
+                if (std::strtof(cand, nullptr) == a) {
+                    digits = std::to_string(mm);
+                    e10 = e + ((int)digits.size() - n);                  // m + 1 may have gained a digit (999 -> 1000)
+                    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+                    break;
+                }
+            }
+        }
+        const int n = (int)digits.size(), k = e10 - (n - 1), kk = e10 + 1;
+        std::string body;
+        if (0 <= k && kk <= 13) body = digits + std::string((size_t)k, '0') + ".0";
+        else if (0 < kk && kk <= 13) body = digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+        else if (-6 < kk && kk <= 0) body = "0." + std::string((size_t)-kk, '0') + digits;
+        else if (n == 1) body = digits + "e" + std::to_string(kk - 1);
+        else body = digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
+        return sign + body;
+    }
+
+    // to_json (edit.rs:105-107): {"exposure":0.0,...} in serde's field order, every f32 in ryu's text (byte-identical to
+    // serde_json's output, exponent forms included); a non-finite value is `null`, as serde_json writes it.
     std::string to_json() const
     {
         std::string s = "{";
         for (int i = 0; i < 10; ++i) {
-            char buf[64];
             const float v = begin()[i];
-            if (!std::isfinite(v)) std::snprintf(buf, sizeof buf, "null");
-            else {
-                int prec = 1;
-                for (; prec < 10; ++prec) {                              // shortest %.Ng that round-trips
-                    std::snprintf(buf, sizeof buf, "%.*g", prec, (double)v);
-                    if (std::strtof(buf, nullptr) == v) break;
-                }
-                if (!std::strpbrk(buf, ".eE")) std::strcat(buf, ".0");
-            }
-            s += std::string(i ? "," : "") + "\"" + kFields[i] + "\":" + buf;
+            s += std::string(i ? "," : "") + "\"" + kFields[i] + "\":" + (std::isfinite(v) ? ryu_f32(v) : std::string("null"));
         }
         return s + "}";
     }
@@ -284,6 +321,14 @@ public:
     {
         std::array<std::array<uint64_t, 256>, 3> h;
         check(rd_node_batch_histogram(h_, &h[0][0]));
+        return h;
+    }
+    // the two halves (no drain between develop calls): enqueue now, fetch the last enqueue's result later
+    void histogram_enqueue() { check(rd_node_batch_histogram_enqueue(h_)); }
+    std::array<std::array<uint64_t, 256>, 3> histogram_fetch()
+    {
+        std::array<std::array<uint64_t, 256>, 3> h;
+        check(rd_node_batch_histogram_fetch(h_, &h[0][0]));
         return h;
     }
     void synchronize() { check(rd_node_batch_synchronize(h_)); }

@@ -9,7 +9,9 @@ import sys
 from .build import LIB_PATH
 
 RD_OK = 0
-ABI_VERSION = 3          # include/rawdev.h RD_ABI_VERSION
+RD_ERR_INVALID_ARG, RD_ERR_NO_DEVICE, RD_ERR_HIP, RD_ERR_OOM, RD_ERR_UNSUPPORTED, RD_ERR_INTERNAL = -1, -2, -3, -4, -5, -6   # rd_status
+FAULT_BAD_ALLOC, FAULT_THREAD_START, FAULT_RUNTIME, FAULT_FOREIGN = 1, 2, 3, 4                                            # rd_fault_kind
+ABI_VERSION = 4          # include/rawdev.h RD_ABI_VERSION
 FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8, FMT_RGB_U8 = 0, 1, 2, 3
 MATH_STRICT, MATH_CONTRACTED = 0, 1
 MATRIX_REFERENCE, MATRIX_ROW_MAJOR = 0, 1
@@ -87,6 +89,8 @@ PROTOTYPES = {
     "rd_node_batch_device_of": (_U32, [_U32, _SZ]),
     "rd_node_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32]),
     "rd_node_batch_histogram": (_I, [_VP, _VP]),
+    "rd_node_batch_histogram_enqueue": (_I, [_VP]),
+    "rd_node_batch_histogram_fetch": (_I, [_VP, _VP]),
     "rd_node_batch_synchronize": (_I, [_VP]),
     "rd_node_batch_stream": (_VP, [_VP, _U32]),
     "rd_node_batch_last_launch_count": (_U32, [_VP, _U32]),
@@ -126,6 +130,7 @@ PROTOTYPES = {
     "rd_debug_lane_count": (_U32, [_VP]),
     "rd_debug_is_pinned_host": (_I, [_VP, _SZ]),
     "rd_debug_node_histogram_of": (_I, [_VP, _U32, _VP]),
+    "rd_debug_inject_fault": (_I, [C.c_char_p, _U32, _U32]),
 }
 
 _lib = None
@@ -172,6 +177,12 @@ def lib():
 def check(code: int) -> None:
     if code != RD_OK:
         raise RawdevError(code, lib().rd_last_error().decode("utf-8", "replace"))
+
+
+def inject_fault(site, kind: int = FAULT_BAD_ALLOC, after: int = 0) -> None:
+    """Test hook (rd_debug_inject_fault): the (after + 1)-th passage through fault point `site` throws a C++ exception of
+    `kind` inside the library, once; the entry point must turn it into a status.  site None disarms."""
+    check(lib().rd_debug_inject_fault(site.encode() if site else None, int(kind), int(after)))
 
 
 def device_count() -> int:

@@ -64,6 +64,17 @@ class NodeBatch:
         check(_lib.lib().rd_node_batch_histogram(self._h, out.ctypes.data_as(C.c_void_p)))
         return out.reshape(3, 256)
 
+    def histogram_enqueue(self) -> None:
+        """Fold + all-reduce + read-back enqueued on the devices' streams; nothing is waited for."""
+        check(_lib.lib().rd_node_batch_histogram_enqueue(self._h))
+
+    def histogram_fetch(self):
+        """The last histogram_enqueue()'s (3, 256) uint64 result; waits for its read-back only."""
+        import numpy as np
+        out = np.zeros(768, np.uint64)
+        check(_lib.lib().rd_node_batch_histogram_fetch(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(3, 256)
+
     def synchronize(self) -> None:
         check(_lib.lib().rd_node_batch_synchronize(self._h))
 

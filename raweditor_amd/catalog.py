@@ -47,13 +47,36 @@ def has_edits(conn: sqlite3.Connection, image_id: int) -> bool:        # library
 
 
 def init_schema(conn: sqlite3.Connection) -> None:
-    """The two tables of library.rs:56-78 (only what the export path reads)."""
+    """Library::init_schema (library.rs:52-121), statement for statement, so that a catalog created here opens in the app
+    unchanged: the two tables, their indexes, the columns the app adds with ALTER TABLE (the three cache tiers of "Phase 28"
+    and file_status; like the app, an "already exists" error from a second run is ignored) and the cache_status index."""
     conn.execute("""CREATE TABLE IF NOT EXISTS images (
-        id INTEGER PRIMARY KEY AUTOINCREMENT, path TEXT NOT NULL UNIQUE, filename TEXT NOT NULL,
-        width INTEGER, height INTEGER, imported_at INTEGER NOT NULL, cache_status TEXT DEFAULT 'pending')""")
+                id              INTEGER PRIMARY KEY AUTOINCREMENT,
+                path            TEXT NOT NULL UNIQUE,
+                filename        TEXT NOT NULL,
+                width           INTEGER,
+                height          INTEGER,
+                imported_at     INTEGER NOT NULL,
+                cache_status    TEXT DEFAULT 'pending'
+            )""")                                                                       # library.rs:56-66
     conn.execute("""CREATE TABLE IF NOT EXISTS edits (
-        id INTEGER PRIMARY KEY AUTOINCREMENT, image_id INTEGER NOT NULL, settings_json TEXT NOT NULL,
-        FOREIGN KEY(image_id) REFERENCES images(id) ON DELETE CASCADE)""")
+                id              INTEGER PRIMARY KEY AUTOINCREMENT,
+                image_id        INTEGER NOT NULL,
+                settings_json   TEXT NOT NULL,
+                FOREIGN KEY(image_id) REFERENCES images(id) ON DELETE CASCADE
+            )""")                                                                       # library.rs:70-78
+    conn.execute("CREATE INDEX IF NOT EXISTS idx_images_imported_at ON images(imported_at DESC)")     # library.rs:81-85
+    conn.execute("CREATE INDEX IF NOT EXISTS idx_edits_image_id ON edits(image_id)")                  # library.rs:87-91
+    for ddl in ("ALTER TABLE images ADD COLUMN cache_path_thumb TEXT",                                 # library.rs:95-106
+                "ALTER TABLE images ADD COLUMN cache_path_instant TEXT",
+                "ALTER TABLE images ADD COLUMN cache_path_working TEXT",
+                "ALTER TABLE images ADD COLUMN file_status TEXT DEFAULT 'exists'"):                   # library.rs:109-112
+        try:
+            conn.execute(ddl)
+        except sqlite3.OperationalError as e:                    # `let _ = self.conn.execute(...)`: the column is there already
+            if "duplicate column" not in str(e):
+                raise
+    conn.execute("CREATE INDEX IF NOT EXISTS idx_images_cache_status ON images(cache_status)")        # library.rs:115-119
     conn.commit()
 
 

@@ -18,6 +18,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -25,8 +26,11 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <memory>
 #include <new>
+#include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -58,11 +62,106 @@ static int rd_fail(int code, const char *fmt, ...)
                            "%s failed: %s", #call, hipGetErrorString(e_));                        \
     } while (0)
 
-extern "C" int rd_abi_version(void) { return RD_ABI_VERSION; }
-extern "C" const char *rd_last_error(void) { return g_err; }
-
-extern "C" int rd_device_count(int *count)
+// ------------------------------------------------------------------------------------------------
+// No C++ exception crosses the C ABI ("Errors": never abort, never throw across the ABI; the
+// reference's constructor returns Result<Self, String>, pipeline.rs:122, :156, :169).
+//
+// Every extern "C" definition of this library is a function-try-block that ends in RD_CATCH_INT / _VOID / _VAL: whatever
+// the body throws -- std::bad_alloc from a growing vector, std::system_error from a thread or mutex, anything else -- becomes
+// a status (RD_ERR_OOM / RD_ERR_INTERNAL) and a message in rd_last_error(); destructors of the body's locals (lock guards,
+// device guards, the owning pointers of half-built objects) have run by then.  tests/test_host_cpu.py checks the source: no
+// extern "C" without the pattern.
+//
+// RD_ENTRY(name) is a FAULT POINT: a place where a test can make the library throw, to prove the above (and that the
+// object at hand stays usable).  rd_debug_inject_fault(site, kind, after) -- or RD_FAULT_INJECT=site:kind[:after] in the
+// environment -- arms one fault: the (after + 1)-th passage through a fault point whose name is `site` ("*" = any) throws
+// once and disarms.  Beside the entry points there are fault points at the places that really allocate or start threads
+// (RD_FAULT_POINT("node.thread"), "batch.descs", "pipeline.lanes", ...).  Unarmed, a fault point is one relaxed load.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct rd_fault_state {
+    std::atomic<uint32_t> armed{ 0 };
+    std::mutex mu;
+    char site[64] = "";
+    uint32_t kind = 0, after = 0;
+};
+rd_fault_state &rd_fault()
 {
+    static rd_fault_state st;
+    return st;
+}
+struct rd_injected_fault {};                                     // RD_FAULT_FOREIGN: not derived from std::exception
+
+void rd_fault_arm(const char *site, uint32_t kind, uint32_t after)
+{
+    rd_fault_state &st = rd_fault();
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (!site || !*site || !kind) { st.armed.store(0, std::memory_order_relaxed); st.site[0] = 0; return; }
+    snprintf(st.site, sizeof st.site, "%s", site);
+    st.kind = kind; st.after = after;
+    st.armed.store(1, std::memory_order_release);
+}
+
+[[gnu::noinline]] void rd_fault_fire(const char *site)
+{
+    rd_fault_state &st = rd_fault();
+    uint32_t kind = 0;
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        if (!st.armed.load(std::memory_order_relaxed)) return;
+        if (strcmp(st.site, "*") != 0 && strcmp(st.site, site) != 0) return;
+        if (st.after) { st.after -= 1; return; }
+        kind = st.kind;
+        st.armed.store(0, std::memory_order_relaxed);            // one shot
+    }
+    switch (kind) {
+    case RD_FAULT_BAD_ALLOC: throw std::bad_alloc();
+    case RD_FAULT_THREAD_START: throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "injected thread-start failure");
+    case RD_FAULT_RUNTIME: throw std::runtime_error(std::string("injected fault at ") + site);
+    default: throw rd_injected_fault{};
+    }
+}
+
+inline void rd_fault_point(const char *site)
+{
+    if (__builtin_expect(rd_fault().armed.load(std::memory_order_relaxed) != 0, 0)) rd_fault_fire(site);
+}
+
+const int rd_fault_env_init = [] {                               // RD_FAULT_INJECT=site:kind[:after]
+    const char *e = getenv("RD_FAULT_INJECT");
+    if (!e || !*e) return 0;
+    char site[64];
+    unsigned kind = 0, after = 0;
+    const char *c = strchr(e, ':');
+    if (!c || (size_t)(c - e) >= sizeof site) return 0;
+    memcpy(site, e, (size_t)(c - e)); site[c - e] = 0;
+    if (sscanf(c + 1, "%u:%u", &kind, &after) < 1) return 0;
+    rd_fault_arm(site, kind, after);
+    return 1;
+}();
+
+// The handler of every entry point (a Lippincott function: rethrows the exception in flight to sort it).
+int rd_caught(const char *name) noexcept
+{
+    try { throw; }
+    catch (const std::bad_alloc &) { return rd_fail(RD_ERR_OOM, "%s: host allocation failed (std::bad_alloc)", name); }
+    catch (const std::exception &e) { return rd_fail(RD_ERR_INTERNAL, "%s: C++ exception stopped at the C boundary: %s", name, e.what()); }
+    catch (...) { return rd_fail(RD_ERR_INTERNAL, "%s: unknown C++ exception stopped at the C boundary", name); }
+}
+}  // namespace
+
+#define RD_FAULT_POINT(site) rd_fault_point(site)
+#define RD_ENTRY(name) rd_fault_point(#name)
+#define RD_CATCH_INT(name) catch (...) { return rd_caught(#name); }
+#define RD_CATCH_VOID(name) catch (...) { (void)rd_caught(#name); }
+#define RD_CATCH_VAL(name, value) catch (...) { (void)rd_caught(#name); return value; }
+
+extern "C" int rd_abi_version(void) try { return RD_ABI_VERSION; } RD_CATCH_INT(rd_abi_version)
+extern "C" const char *rd_last_error(void) try { return g_err; } RD_CATCH_VAL(rd_last_error, g_err)      // (no fault point: it would overwrite what it returns)
+
+extern "C" int rd_device_count(int *count) try
+{
+    RD_ENTRY(rd_device_count);
     if (!count) return rd_fail(RD_ERR_INVALID_ARG, "rd_device_count: count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -70,10 +169,12 @@ extern "C" int rd_device_count(int *count)
     *count = n;
     return RD_OK;
 }
+RD_CATCH_INT(rd_device_count)
 
 // PCI bus id ("0000:c1:00.0") and marketing name of a visible device: what tells two ranks of a multi-GPU run apart.
-extern "C" int rd_device_identity(int device, char *pci_bus_id, size_t pci_cap, char *name, size_t name_cap)
+extern "C" int rd_device_identity(int device, char *pci_bus_id, size_t pci_cap, char *name, size_t name_cap) try
 {
+    RD_ENTRY(rd_device_identity);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return rd_fail(RD_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n) return rd_fail(RD_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
@@ -83,16 +184,20 @@ extern "C" int rd_device_identity(int device, char *pci_bus_id, size_t pci_cap, 
     if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
     return RD_OK;
 }
+RD_CATCH_INT(rd_device_identity)
 
-extern "C" void rd_edit_params_default(rd_edit_params *p)
+extern "C" void rd_edit_params_default(rd_edit_params *p) try
 {
+    RD_ENTRY(rd_edit_params_default);
     if (!p) return;
     memset(p, 0, sizeof *p);   // edit.rs:81-95
     p->whites = 1.0f;
 }
+RD_CATCH_VOID(rd_edit_params_default)
 
-extern "C" int rd_derived_dims(uint32_t w, uint32_t h, uint32_t *pw, uint32_t *ph, uint32_t *hw, uint32_t *hh)
+extern "C" int rd_derived_dims(uint32_t w, uint32_t h, uint32_t *pw, uint32_t *ph, uint32_t *hw, uint32_t *hh) try
 {
+    RD_ENTRY(rd_derived_dims);
     if (!w || !h || !pw || !ph || !hw || !hh) return rd_fail(RD_ERR_INVALID_ARG, "rd_derived_dims: bad argument");
     // pipeline.rs:125-133, same truncating f32 arithmetic
     const float aspect = (float)w / (float)h;
@@ -103,17 +208,22 @@ extern "C" int rd_derived_dims(uint32_t w, uint32_t h, uint32_t *pw, uint32_t *p
     *hh = (uint32_t)((float)128u / aspect);
     return RD_OK;
 }
+RD_CATCH_INT(rd_derived_dims)
 
-extern "C" size_t rd_format_bytes_per_pixel(uint32_t f)
+extern "C" size_t rd_format_bytes_per_pixel(uint32_t f) try
 {
+    RD_ENTRY(rd_format_bytes_per_pixel);
     return f == RD_FMT_RGBA_F32 ? 16 : f == RD_FMT_RGBA_F16 ? 8 : f == RD_FMT_RGBA_U8 ? 4 : f == RD_FMT_RGB_U8 ? 3 : 0;
 }
+RD_CATCH_VAL(rd_format_bytes_per_pixel, 0)
 
-extern "C" uint32_t rd_elided_steps(const rd_edit_params *p, const float wb[4], const float cm[9], uint32_t math_mode)
+extern "C" uint32_t rd_elided_steps(const rd_edit_params *p, const float wb[4], const float cm[9], uint32_t math_mode) try
 {
+    RD_ENTRY(rd_elided_steps);
     if (!p || !wb || !cm) return 0u;
     return rd_make_ku(*p, wb, cm, 1.0f, 0.0f, 0.0f, 0u, math_mode).elide;
 }
+RD_CATCH_VAL(rd_elided_steps, 0)
 
 // ------------------------------------------------------------------------------------------------
 // device bookkeeping
@@ -254,6 +364,7 @@ struct rd_scratch {
     std::mutex mu;
     std::vector<entry> ents;
     uint64_t clock = 0;
+    rd_scratch() { ents.reserve(max_entries); }                  // so that no push_back below can throw with device memory in hand
 
     // The entry of stream s, created / recycled / re-zeroed as needed.  idx < 0: allocation failed.
     lease get(hipStream_t s, bool want_slab)
@@ -263,6 +374,7 @@ struct rd_scratch {
         for (size_t i = 0; i < ents.size(); ++i)
             if (ents[i].stream == s) idx = (int)i;
         if (idx < 0 && ents.size() < max_entries) {
+            RD_FAULT_POINT("scratch.entry");
             entry e;
             if (hipMalloc((void **)&e.tq, tq_bytes) != hipSuccess) return lease{};
             if (hipMemset(e.tq, 0, tq_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
@@ -501,8 +613,9 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
 // ingest helper: lossless-JPEG tiles of compressed DNGs (host code; rd_ljpeg.h)
 // ------------------------------------------------------------------------------------------------
 extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, size_t dst_capacity_samples, uint32_t *width,
-                               uint32_t *height, uint32_t *components, uint32_t *precision)
+                               uint32_t *height, uint32_t *components, uint32_t *precision) try
 {
+    RD_ENTRY(rd_ljpeg_decode);
     if (!src || (!dst && dst_capacity_samples)) return rd_fail(RD_ERR_INVALID_ARG, "rd_ljpeg_decode: NULL argument");
     if (width) *width = 0;
     if (height) *height = 0;
@@ -517,21 +630,25 @@ extern "C" int rd_ljpeg_decode(const uint8_t *src, size_t len, uint16_t *dst, si
     default: return rd_fail(RD_ERR_INVALID_ARG, "Failed to decode RAW: malformed lossless-JPEG stream");
     }
 }
+RD_CATCH_INT(rd_ljpeg_decode)
 
 // ------------------------------------------------------------------------------------------------
 // plumbing
 // ------------------------------------------------------------------------------------------------
-extern "C" int rd_device_malloc(int device, size_t bytes, void **out)
+extern "C" int rd_device_malloc(int device, size_t bytes, void **out) try
 {
+    RD_ENTRY(rd_device_malloc);
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipMalloc(out, bytes ? bytes : 1));
     return RD_OK;
 }
+RD_CATCH_INT(rd_device_malloc)
 
-extern "C" int rd_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
+extern "C" int rd_device_memory(int device, size_t *free_bytes, size_t *total_bytes) try
 {
+    RD_ENTRY(rd_device_memory);
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     size_t f = 0, t = 0;
@@ -540,34 +657,42 @@ extern "C" int rd_device_memory(int device, size_t *free_bytes, size_t *total_by
     if (total_bytes) *total_bytes = t;
     return RD_OK;
 }
+RD_CATCH_INT(rd_device_memory)
 
-extern "C" int rd_device_free(int device, void *ptr)
+extern "C" int rd_device_free(int device, void *ptr) try
 {
+    RD_ENTRY(rd_device_free);
     if (!ptr) return RD_OK;
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipFree(ptr));
     return RD_OK;
 }
+RD_CATCH_INT(rd_device_free)
 
-extern "C" int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes)
+extern "C" int rd_memcpy_h2d(int device, void *dst_dev, const void *src, size_t bytes) try
 {
+    RD_ENTRY(rd_memcpy_h2d);
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice));
     return RD_OK;
 }
+RD_CATCH_INT(rd_memcpy_h2d)
 
-extern "C" int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t bytes)
+extern "C" int rd_memcpy_d2h(int device, void *dst, const void *src_dev, size_t bytes) try
 {
+    RD_ENTRY(rd_memcpy_d2h);
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
     return RD_OK;
 }
+RD_CATCH_INT(rd_memcpy_d2h)
 
-extern "C" int rd_stream_create(int device, void **out)
+extern "C" int rd_stream_create(int device, void **out) try
 {
+    RD_ENTRY(rd_stream_create);
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
@@ -576,16 +701,19 @@ extern "C" int rd_stream_create(int device, void **out)
     *out = (void *)s;
     return RD_OK;
 }
+RD_CATCH_INT(rd_stream_create)
 
-extern "C" int rd_stream_synchronize(int device, void *stream)
+extern "C" int rd_stream_synchronize(int device, void *stream) try
 {
+    RD_ENTRY(rd_stream_synchronize);
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipStreamSynchronize((hipStream_t)stream));
     return RD_OK;
 }
+RD_CATCH_INT(rd_stream_synchronize)
 
-extern "C" int rd_stream_destroy(int device, void *stream)
+extern "C" int rd_stream_destroy(int device, void *stream) try
 {
     if (!stream) return RD_OK;
     rd_devguard g(device);
@@ -593,10 +721,12 @@ extern "C" int rd_stream_destroy(int device, void *stream)
     RD_HIP(hipStreamDestroy((hipStream_t)stream));
     return RD_OK;
 }
+RD_CATCH_INT(rd_stream_destroy)
 
 // Test hooks (declared in rawdev.h under "test hooks"): never needed by a host.
-extern "C" int rd_debug_poison_scheduler(rd_pipeline *p, void *stream)
+extern "C" int rd_debug_poison_scheduler(rd_pipeline *p, void *stream) try
 {
+    RD_ENTRY(rd_debug_poison_scheduler);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     rd_devguard g(p->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
@@ -605,23 +735,38 @@ extern "C" int rd_debug_poison_scheduler(rd_pipeline *p, void *stream)
     if (!p->scratch.poison(s)) return rd_fail(RD_ERR_INVALID_ARG, "this pipeline holds no scheduler state for that stream yet");
     return RD_OK;
 }
+RD_CATCH_INT(rd_debug_poison_scheduler)
 
-extern "C" uint32_t rd_debug_scheduler_entries(rd_pipeline *p) { return p ? (uint32_t)p->scratch.size() : 0u; }
+extern "C" uint32_t rd_debug_scheduler_entries(rd_pipeline *p) try { RD_ENTRY(rd_debug_scheduler_entries); return p ? (uint32_t)p->scratch.size() : 0u; } RD_CATCH_VAL(rd_debug_scheduler_entries, 0)
 
 // render lanes this pipeline has created so far (<= RD_LANES_MAX), and whether a host range would take the direct-DMA path
-extern "C" uint32_t rd_debug_lane_count(rd_pipeline *p)
+extern "C" uint32_t rd_debug_lane_count(rd_pipeline *p) try
 {
+    RD_ENTRY(rd_debug_lane_count);
     if (!p) return 0u;
     std::lock_guard<std::mutex> lk(p->lane_mu);
     return (uint32_t)p->lanes.size();
 }
+RD_CATCH_VAL(rd_debug_lane_count, 0)
 
-extern "C" int rd_debug_is_pinned_host(const void *ptr, size_t len) { return ptr && rd_is_pinned_host(ptr, len) ? 1 : 0; }
+extern "C" int rd_debug_is_pinned_host(const void *ptr, size_t len) try { RD_ENTRY(rd_debug_is_pinned_host); return ptr && rd_is_pinned_host(ptr, len) ? 1 : 0; } RD_CATCH_INT(rd_debug_is_pinned_host)
 
-extern "C" int rd_device_synchronize(int device)
+// Arm (kind != 0) or disarm (site NULL / empty, or kind 0) the one-shot injected fault described at the top of this file.
+extern "C" int rd_debug_inject_fault(const char *site, uint32_t kind, uint32_t after) try
 {
+    if (kind > RD_FAULT_FOREIGN) return rd_fail(RD_ERR_INVALID_ARG, "unknown fault kind %u", kind);
+    if (site && strlen(site) >= 64) return rd_fail(RD_ERR_INVALID_ARG, "site name too long");
+    rd_fault_arm(site, kind, after);
+    return RD_OK;
+}
+RD_CATCH_INT(rd_debug_inject_fault)
+
+extern "C" int rd_device_synchronize(int device) try
+{
+    RD_ENTRY(rd_device_synchronize);
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipDeviceSynchronize());
     return RD_OK;
 }
+RD_CATCH_INT(rd_device_synchronize)

@@ -40,8 +40,9 @@ struct rd_batch {
 };
 
 extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
-                               rd_batch **out)
+                               rd_batch **out) try
 {
+    RD_ENTRY(rd_batch_create);
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
@@ -60,12 +61,14 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (rc) return rc;
     rd_batch *b = new (std::nothrow) rd_batch;
     if (!b) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    struct undo { void operator()(rd_batch *q) const { rd_batch_destroy(q); } };
+    std::unique_ptr<rd_batch, undo> hold(b);                     // whatever fails or throws below: the half-built batch is destroyed
     b->device = device; b->w = w; b->h = h; b->fmt = fmt; b->hist = with_histogram != 0;
     b->cfg.n_cu = n_cu;
     b->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
     b->cfg.wg_per_cu_hist = rd_env_u32("RD_WG_PER_CU_HIST", 2);      // experiment builds with a smaller RD_BLOCK only
     b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
-    if (!b->identity_ok) { delete b; return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h); }
+    if (!b->identity_ok) return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h);
     b->blocks = rd_blocks_for(b->cfg, items, b->hist);
     b->n_streams = rd_env_u32("RD_BATCH_STREAMS", 1) >= 2 ? 2u : 1u;
     {
@@ -90,16 +93,13 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
         e = hipMalloc((void **)&b->slab64, bytes);
         if (e == hipSuccess) e = hipMemset(b->slab64, 0, bytes);
     }
-    if (e != hipSuccess) {
-        const int code = rd_fail(RD_ERR_OOM, "batch resources: %s", hipGetErrorString(e));
-        rd_batch_destroy(b);
-        return code;
-    }
-    *out = b;
+    if (e != hipSuccess) return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "batch resources: %s", hipGetErrorString(e));
+    *out = hold.release();
     return RD_OK;
 }
+RD_CATCH_INT(rd_batch_create)
 
-extern "C" void rd_batch_destroy(rd_batch *b)
+extern "C" void rd_batch_destroy(rd_batch *b) try
 {
     if (!b) return;
     {
@@ -119,14 +119,17 @@ extern "C" void rd_batch_destroy(rd_batch *b)
     }
     delete b;
 }
+RD_CATCH_VOID(rd_batch_destroy)
 
-extern "C" int rd_batch_set_math_mode(rd_batch *b, uint32_t mode)
+extern "C" int rd_batch_set_math_mode(rd_batch *b, uint32_t mode) try
 {
+    RD_ENTRY(rd_batch_set_math_mode);
     if (!b) return rd_fail(RD_ERR_INVALID_ARG, "NULL batch");
     if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
     b->math_mode = mode;
     return RD_OK;
 }
+RD_CATCH_INT(rd_batch_set_math_mode)
 
 // How many frames one multi-frame launch may hold for frames of w x h: the 32-bit tile index, the u32 histogram bins a
 // workgroup keeps in LDS for the whole launch (every pixel of the launch could, in principle, land in one bin of one
@@ -163,8 +166,9 @@ static size_t rd_next_launch_size(const rd_frame *frames, size_t n, size_t i0, s
 // of launches, or a negative rd_status; at most `counts_cap` entries are written.
 extern "C" int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t format, uint32_t with_histogram,
                                       const rd_frame *frames, size_t n_frames, uint32_t max_frames, uint32_t *counts,
-                                      size_t counts_cap)
+                                      size_t counts_cap) try
 {
+    RD_ENTRY(rd_batch_plan_launches);
     const size_t bpp = rd_format_bytes_per_pixel(format);
     if (!width || !height || !bpp || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "rd_batch_plan_launches: bad argument");
     const uint32_t cap = max_frames ? max_frames : (format == RD_FMT_RGBA_F32 ? 8u : 32u);
@@ -179,6 +183,7 @@ extern "C" int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t 
     }
     return launches;
 }
+RD_CATCH_INT(rd_batch_plan_launches)
 
 // The multi-frame path of rd_batch_develop: descriptors -> HBM (only when they changed), then as few launches as the
 // limits allow.  A launch never holds two frames whose surfaces overlap (the order in which the tiles of DIFFERENT frames
@@ -191,6 +196,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     const size_t bpp = rd_format_bytes_per_pixel(b->fmt);
     const size_t surf_bytes = (size_t)b->w * b->h * bpp;
     static thread_local std::vector<rd_frame_desc> tmp;
+    RD_FAULT_POINT("batch.descs");
     tmp.resize(n);
     memset(tmp.data(), 0, n * sizeof(rd_frame_desc));
     bool aligned16 = true;
@@ -258,8 +264,9 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     return rc;
 }
 
-extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, uint32_t row_bands, void *stream)
+extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, uint32_t row_bands, void *stream) try
 {
+    RD_ENTRY(rd_batch_develop);
     if (!b || (!frames && n)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
@@ -306,11 +313,13 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
     }
     return rc;
 }
+RD_CATCH_INT(rd_batch_develop)
 
-extern "C" uint32_t rd_batch_last_launch_count(const rd_batch *b) { return b ? b->last_launches : 0u; }
+extern "C" uint32_t rd_batch_last_launch_count(const rd_batch *b) try { RD_ENTRY(rd_batch_last_launch_count); return b ? b->last_launches : 0u; } RD_CATCH_VAL(rd_batch_last_launch_count, 0)
 
-extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
+extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream) try
 {
+    RD_ENTRY(rd_batch_histogram);
     if (!b || !hist_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     if (!b->hist) return rd_fail(RD_ERR_INVALID_ARG, "batch was created without a histogram");
     rd_devguard g(b->device);
@@ -320,6 +329,7 @@ extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream)
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
+RD_CATCH_INT(rd_batch_histogram)
 
 // ------------------------------------------------------------------------------------------------
 // rd_node_batch: the batch path over the GPUs of one node from ONE process (SURVEY.md section 8b "Batch", 8e)
@@ -387,6 +397,64 @@ rd_rccl_api &rd_rccl()
 
 enum { RD_NODE_REDUCE_NONE = 0, RD_NODE_REDUCE_RCCL = 1, RD_NODE_REDUCE_HOST = 2 };
 
+// One host thread per device, for the life of the node batch (round 5; rounds 2-4 started and joined N threads inside every
+// rd_node_batch_develop call -- 20 ms apart in the bench -- and a thread that failed to start there took the process down:
+// the already started ones were destroyed joinable).  A worker sleeps on its condition variable, runs the job it is handed
+// -- a plain function pointer + context: posting allocates nothing and cannot throw -- inside its own catch-all, and
+// reports status + message.  Its device is current for its whole life, so the per-call device guard finds nothing to do.
+struct rd_node_worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int (*call)(void *ctx, uint32_t d) = nullptr;
+    void *ctx = nullptr;
+    uint32_t index = 0;
+    int device = 0;
+    bool has_job = false, done = false, quit = false;
+    int rc = RD_OK;
+    char msg[sizeof g_err] = "";
+
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return has_job || quit; });
+            if (quit) return;
+            has_job = false;
+            int (*fn)(void *, uint32_t) = call;
+            void *c = ctx;
+            lk.unlock();
+            int r;
+            try { r = fn(c, index); }
+            catch (...) { r = rd_caught("rd_node_batch worker"); }           // nothing leaves a thread either: that would be std::terminate
+            lk.lock();
+            rc = r;
+            snprintf(msg, sizeof msg, "%s", r ? rd_last_error() : "");
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(int (*fn)(void *, uint32_t), void *c)
+    {
+        { std::lock_guard<std::mutex> lk(mu); call = fn; ctx = c; done = false; has_job = true; }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return done; });
+        return rc;
+    }
+    void stop()
+    {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
+
 struct rd_node_batch {
     uint32_t n = 0, w = 0, h = 0, fmt = 0;
     bool hist = false;
@@ -395,18 +463,27 @@ struct rd_node_batch {
     std::vector<rd_batch *> batches;
     std::vector<hipStream_t> streams;
     std::vector<uint64_t *> hist_dev;          // 768 x u64 per device
+    uint64_t *hist_pin = nullptr;              // page-locked, n x 768: where rd_node_batch_histogram_enqueue's read-backs land
+    std::vector<hipEvent_t> hist_ready;        // per device: its read-back has landed
+    uint32_t hist_pending = 0;                 // devices whose read-back the next fetch waits for (0: nothing enqueued)
     std::vector<void *> comms;                 // ncclComm_t per device (RCCL only)
     std::vector<std::vector<rd_frame>> share;  // the frames of the current call, per device
+    std::unique_ptr<rd_node_worker[]> workers; // n of them when n > 1 (a single device is served by the calling thread)
+    std::mutex call_mu;                        // one rd_node_batch_develop at a time (the workers hold one job each)
 };
 
-extern "C" uint32_t rd_node_batch_device_of(uint32_t n_devices, size_t frame_index)
+extern "C" uint32_t rd_node_batch_device_of(uint32_t n_devices, size_t frame_index) try
 {
+    RD_ENTRY(rd_node_batch_device_of);
     return n_devices ? (uint32_t)(frame_index % n_devices) : 0u;      // frame i -> GPU i mod N
 }
+RD_CATCH_VAL(rd_node_batch_device_of, 0)
 
-extern "C" void rd_node_batch_destroy(rd_node_batch *nb)
+extern "C" void rd_node_batch_destroy(rd_node_batch *nb) try
 {
     if (!nb) return;
+    if (nb->workers)
+        for (uint32_t d = 0; d < nb->n; ++d) nb->workers[d].stop();      // join what was started (all of them, or the first k of a failed create)
     for (uint32_t d = 0; d < nb->n; ++d) {
         if (d >= nb->streams.size() || !nb->streams[d]) continue;      // nothing was set up on this entry (failed create)
         rd_devguard g(nb->devices[d]);
@@ -420,14 +497,18 @@ extern "C" void rd_node_batch_destroy(rd_node_batch *nb)
         if (!any) continue;
         rd_devguard g(nb->devices[d]);
         if (nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
+        if (d < nb->hist_ready.size() && nb->hist_ready[d]) (void)hipEventDestroy(nb->hist_ready[d]);
         if (nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
     }
+    if (nb->hist_pin) { rd_devguard g(nb->devices[0]); (void)hipHostFree(nb->hist_pin); }
     delete nb;
 }
+RD_CATCH_VOID(rd_node_batch_destroy)
 
 extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t format,
-                                    uint32_t with_histogram, rd_node_batch **out)
+                                    uint32_t with_histogram, rd_node_batch **out) try
 {
+    RD_ENTRY(rd_node_batch_create);
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!devices || !n_devices || n_devices > 64) return rd_fail(RD_ERR_INVALID_ARG, "need 1..64 devices");
@@ -445,11 +526,14 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
                                            "allows it for rehearsals on a one-GPU box)");
     rd_node_batch *nb = new (std::nothrow) rd_node_batch;
     if (!nb) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    struct undo { void operator()(rd_node_batch *q) const { rd_node_batch_destroy(q); } };
+    std::unique_ptr<rd_node_batch, undo> hold(nb);               // whatever fails or throws below: what exists is torn down, threads joined
     nb->n = n_devices; nb->w = width; nb->h = height; nb->fmt = format; nb->hist = with_histogram != 0;
     nb->devices.assign(devices, devices + n_devices);
     nb->batches.assign(n_devices, nullptr);
     nb->streams.assign(n_devices, nullptr);
     nb->hist_dev.assign(n_devices, nullptr);
+    nb->hist_ready.assign(n_devices, nullptr);
     nb->comms.assign(n_devices, nullptr);
     nb->share.resize(n_devices);
     int rc = RD_OK;
@@ -459,7 +543,9 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
         rd_devguard g(devices[d]);
         hipError_t e = hipStreamCreateWithFlags(&nb->streams[d], hipStreamNonBlocking);
         if (e == hipSuccess && nb->hist) e = hipMalloc((void **)&nb->hist_dev[d], 768 * sizeof(uint64_t));
-        if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "device %d: %s", devices[d], hipGetErrorString(e));
+        if (e == hipSuccess && nb->hist) e = hipEventCreateWithFlags(&nb->hist_ready[d], hipEventDisableTiming);
+        if (e == hipSuccess && nb->hist && d == 0) e = hipHostMalloc((void **)&nb->hist_pin, (size_t)n_devices * 768 * sizeof(uint64_t), hipHostMallocPortable);
+        if (e != hipSuccess) rc = rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "device %d: %s", devices[d], hipGetErrorString(e));
     }
     if (rc == RD_OK && nb->hist) {
         if (want_host) nb->reduce = n_devices > 1 ? RD_NODE_REDUCE_HOST : RD_NODE_REDUCE_NONE;
@@ -473,61 +559,94 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
             }
         }
     }
-    if (rc) { std::string keep = g_err; rd_node_batch_destroy(nb); snprintf(g_err, sizeof g_err, "%s", keep.c_str()); return rc; }
-    *out = nb;
+    if (rc == RD_OK && n_devices > 1) {                          // the workers: a thread that cannot be started is a status, not a terminate
+        nb->workers.reset(new rd_node_worker[n_devices]);
+        for (uint32_t d = 0; d < n_devices; ++d) {
+            rd_node_worker &w = nb->workers[d];
+            w.index = d; w.device = devices[d];
+            try {
+                RD_FAULT_POINT("node.thread");
+                w.th = std::thread([&w] { w.loop(); });
+            } catch (const std::exception &e) {
+                rc = rd_fail(RD_ERR_INTERNAL, "cannot start the host thread of device %d (%u of %u): %s", devices[d], d + 1u, n_devices, e.what());
+                break;
+            }
+        }
+    }
+    if (rc) {                                                    // the teardown (hold) may overwrite the message: keep it
+        char keep[sizeof g_err];
+        snprintf(keep, sizeof keep, "%s", g_err);
+        hold.reset();
+        snprintf(g_err, sizeof g_err, "%s", keep);
+        return rc;
+    }
+    *out = hold.release();
     return RD_OK;
 }
+RD_CATCH_INT(rd_node_batch_create)
 
-extern "C" int rd_node_batch_set_math_mode(rd_node_batch *nb, uint32_t mode)
+extern "C" int rd_node_batch_set_math_mode(rd_node_batch *nb, uint32_t mode) try
 {
+    RD_ENTRY(rd_node_batch_set_math_mode);
     if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
     for (rd_batch *b : nb->batches) { int rc = rd_batch_set_math_mode(b, mode); if (rc) return rc; }
     return RD_OK;
 }
+RD_CATCH_INT(rd_node_batch_set_math_mode)
 
-// run fn(d) for every device, on one host thread per device when there is more than one; first error wins
+// run fn(d) for every device -- on the device's worker thread when there is more than one; first error wins.  Nothing here
+// allocates or starts a thread: the job is a pointer to the caller's functor, which outlives the wait below.
 template <typename F> static int rd_node_for_each(rd_node_batch *nb, F fn)
 {
-    if (nb->n == 1) return fn(0u);
-    std::vector<int> rcs(nb->n, RD_OK);
-    std::vector<std::string> msgs(nb->n);
-    std::vector<std::thread> th;
-    th.reserve(nb->n);
-    for (uint32_t d = 0; d < nb->n; ++d)
-        th.emplace_back([&, d] { rcs[d] = fn(d); if (rcs[d]) msgs[d] = rd_last_error(); });
-    for (auto &t : th) t.join();
-    for (uint32_t d = 0; d < nb->n; ++d)
-        if (rcs[d]) return rd_fail(rcs[d], "device %d: %s", nb->devices[d], msgs[d].c_str());
+    if (nb->n == 1 || !nb->workers) return fn(0u);
+    int (*tramp)(void *, uint32_t) = [](void *c, uint32_t d) -> int { return (*static_cast<F *>(c))(d); };
+    for (uint32_t d = 0; d < nb->n; ++d) nb->workers[d].post(tramp, &fn);
+    int first = RD_OK;
+    uint32_t who = 0;
+    for (uint32_t d = 0; d < nb->n; ++d) {                      // wait for ALL of them, whatever the first one says
+        const int rc = nb->workers[d].wait();
+        if (rc && !first) { first = rc; who = d; }
+    }
+    if (first) return rd_fail(first, "device %d: %s", nb->devices[who], nb->workers[who].msg);
     return RD_OK;
 }
 
-extern "C" int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_frames, uint32_t row_bands)
+extern "C" int rd_node_batch_develop(rd_node_batch *nb, const rd_frame *frames, size_t n_frames, uint32_t row_bands) try
 {
+    RD_ENTRY(rd_node_batch_develop);
     if (!nb || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> call(nb->call_mu);
     for (auto &v : nb->share) v.clear();
-    for (size_t i = 0; i < n_frames; ++i) nb->share[rd_node_batch_device_of(nb->n, i)].push_back(frames[i]);
+    RD_FAULT_POINT("node.share");
+    for (size_t i = 0; i < n_frames; ++i) nb->share[i % nb->n].push_back(frames[i]);      // frame i -> GPU i mod N
     return rd_node_for_each(nb, [&](uint32_t d) -> int {
         const std::vector<rd_frame> &v = nb->share[d];
         return v.empty() ? (int)RD_OK : rd_batch_develop(nb->batches[d], v.data(), v.size(), row_bands, nb->streams[d]);
     });
 }
+RD_CATCH_INT(rd_node_batch_develop)
 
-extern "C" void *rd_node_batch_stream(rd_node_batch *nb, uint32_t index)
+extern "C" void *rd_node_batch_stream(rd_node_batch *nb, uint32_t index) try
 {
+    RD_ENTRY(rd_node_batch_stream);
     return nb && index < nb->n ? (void *)nb->streams[index] : nullptr;
 }
+RD_CATCH_VAL(rd_node_batch_stream, nullptr)
 
-extern "C" uint32_t rd_node_batch_last_launch_count(const rd_node_batch *nb, uint32_t index)
+extern "C" uint32_t rd_node_batch_last_launch_count(const rd_node_batch *nb, uint32_t index) try
 {
+    RD_ENTRY(rd_node_batch_last_launch_count);
     return nb && index < nb->n ? rd_batch_last_launch_count(nb->batches[index]) : 0u;
 }
+RD_CATCH_VAL(rd_node_batch_last_launch_count, 0)
 
-extern "C" int rd_node_batch_reduce_kind(const rd_node_batch *nb) { return nb ? nb->reduce : -1; }
+extern "C" int rd_node_batch_reduce_kind(const rd_node_batch *nb) try { RD_ENTRY(rd_node_batch_reduce_kind); return nb ? nb->reduce : -1; } RD_CATCH_INT(rd_node_batch_reduce_kind)
 
 // test hook: what devices[index]'s 768 x u64 buffer holds after the last rd_node_batch_histogram (after an all-reduce
 // every device must hold the global sum, not only the one the call reads back)
-extern "C" int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768])
+extern "C" int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uint64_t hist[768]) try
 {
+    RD_ENTRY(rd_debug_node_histogram_of);
     if (!nb || !hist || index >= nb->n || !nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "rd_debug_node_histogram_of: bad argument");
     rd_devguard g(nb->devices[index]);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[index]);
@@ -535,9 +654,11 @@ extern "C" int rd_debug_node_histogram_of(rd_node_batch *nb, uint32_t index, uin
     RD_HIP(hipStreamSynchronize(nb->streams[index]));
     return RD_OK;
 }
+RD_CATCH_INT(rd_debug_node_histogram_of)
 
-extern "C" int rd_node_batch_synchronize(rd_node_batch *nb)
+extern "C" int rd_node_batch_synchronize(rd_node_batch *nb) try
 {
+    RD_ENTRY(rd_node_batch_synchronize);
     if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL node batch");
     for (uint32_t d = 0; d < nb->n; ++d) {
         rd_devguard g(nb->devices[d]);
@@ -546,12 +667,19 @@ extern "C" int rd_node_batch_synchronize(rd_node_batch *nb)
     }
     return RD_OK;
 }
+RD_CATCH_INT(rd_node_batch_synchronize)
 
-extern "C" int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768])
+// The global histogram in two halves, so that a host which runs step after step need not drain its devices for it (the
+// one-process-per-GPU host never does: its fold and all-reduce are stream-ordered):
+//   enqueue: per-device fold of the slabs into 768 x u64 on each device's stream (behind the launches enqueued there), the
+//            RCCL all-reduce in place (one group), and the read-back into the handle's page-locked buffer -- of device 0
+//            after an all-reduce (every device then holds the sum), of every device for the host fold.  Nothing is waited for.
+//   fetch:   waits for those read-backs only (an event per device, not the streams: develop calls already enqueued behind
+//            them keep running) and hands out the sum.  One result may be outstanding: a second enqueue before the fetch
+//            overwrites the first (its counts are NOT lost -- they were folded into the device buffers and read back -- but
+//            only the last enqueue's result is what fetch returns).
+static int rd_node_histogram_enqueue(rd_node_batch *nb)
 {
-    if (!nb || !hist) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
-    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
-    // per-device fold of the slabs into 768 x u64, on each device's stream (after the launches enqueued there)
     for (uint32_t d = 0; d < nb->n; ++d) {
         int rc = rd_batch_histogram(nb->batches[d], nb->hist_dev[d], nb->streams[d]);
         if (rc) return rc;
@@ -568,17 +696,78 @@ extern "C" int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768])
         if (r != 0) return rd_fail(RD_ERR_HIP, "ncclAllReduce: %s", api.GetErrorString(r));
     }
     const uint32_t take = nb->reduce == RD_NODE_REDUCE_HOST ? nb->n : 1u;      // after an all-reduce every device holds the sum
-    uint64_t part[768];
-    memset(hist, 0, 768 * sizeof(uint64_t));
+    // The read-back is a 768-thread KERNEL that stores into the page-locked buffer (host-coherent, mapped into every device),
+    // not a hipMemcpyAsync: a copy-engine transfer between two kernels of one stream is ordered through signals on both
+    // sides and leaves the compute queue idle meanwhile, once per step (RD_NODE_HIST_DMA=1 keeps that form for A/B).
+    static const bool dma = rd_env_u32("RD_NODE_HIST_DMA", 0) != 0;
+    nb->hist_pending = 0;
     for (uint32_t d = 0; d < take; ++d) {
         rd_devguard g(nb->devices[d]);
         if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
-        RD_HIP(hipMemcpyAsync(part, nb->hist_dev[d], sizeof part, hipMemcpyDeviceToHost, nb->streams[d]));
-        RD_HIP(hipStreamSynchronize(nb->streams[d]));
+        uint64_t *dst = nb->hist_pin + (size_t)d * 768u;
+        if (dma) {
+            RD_HIP(hipMemcpyAsync(dst, nb->hist_dev[d], 768 * sizeof(uint64_t), hipMemcpyDeviceToHost, nb->streams[d]));
+        } else {
+            hipLaunchKernelGGL(rd_copy_hist64, dim3(1), dim3(768), 0, nb->streams[d], (const unsigned long long *)nb->hist_dev[d],
+                               (unsigned long long *)dst);
+            RD_HIP(hipGetLastError());
+        }
+        RD_HIP(hipEventRecord(nb->hist_ready[d], nb->streams[d]));
+        nb->hist_pending = d + 1u;
+    }
+    return RD_OK;
+}
+
+static int rd_node_histogram_fetch(rd_node_batch *nb, uint64_t hist[768])
+{
+    if (!nb->hist_pending) return rd_fail(RD_ERR_INVALID_ARG, "rd_node_batch_histogram_fetch: nothing was enqueued");
+    memset(hist, 0, 768 * sizeof(uint64_t));
+    for (uint32_t d = 0; d < nb->hist_pending; ++d) {
+        rd_devguard g(nb->devices[d]);
+        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
+        RD_HIP(hipEventSynchronize(nb->hist_ready[d]));
+        const uint64_t *part = nb->hist_pin + (size_t)d * 768u;
         for (int k = 0; k < 768; ++k) hist[k] += part[k];
     }
-    return rd_node_batch_synchronize(nb);                      // the call returns with every device's work done
+    nb->hist_pending = 0;
+    return RD_OK;
 }
+
+extern "C" int rd_node_batch_histogram_enqueue(rd_node_batch *nb) try
+{
+    RD_ENTRY(rd_node_batch_histogram_enqueue);
+    if (!nb) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
+    std::lock_guard<std::mutex> call(nb->call_mu);
+    return rd_node_histogram_enqueue(nb);
+}
+RD_CATCH_INT(rd_node_batch_histogram_enqueue)
+
+extern "C" int rd_node_batch_histogram_fetch(rd_node_batch *nb, uint64_t hist[768]) try
+{
+    RD_ENTRY(rd_node_batch_histogram_fetch);
+    if (!nb || !hist) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
+    std::lock_guard<std::mutex> call(nb->call_mu);
+    return rd_node_histogram_fetch(nb, hist);
+}
+RD_CATCH_INT(rd_node_batch_histogram_fetch)
+
+// Both halves and a synchronise: the call returns with every device's work done.
+extern "C" int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768]) try
+{
+    RD_ENTRY(rd_node_batch_histogram);
+    if (!nb || !hist) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (!nb->hist) return rd_fail(RD_ERR_INVALID_ARG, "node batch was created without a histogram");
+    {
+        std::lock_guard<std::mutex> call(nb->call_mu);
+        int rc = rd_node_histogram_enqueue(nb);
+        if (rc == RD_OK) rc = rd_node_histogram_fetch(nb, hist);
+        if (rc) return rc;
+    }
+    return rd_node_batch_synchronize(nb);
+}
+RD_CATCH_INT(rd_node_batch_histogram)
 
 // ------------------------------------------------------------------------------------------------
 // rd_exporter: develop -> HBM slot -> pinned host slot, copy stream overlapping the compute stream
@@ -605,7 +794,7 @@ struct rd_exporter {
     std::mutex mu;
 };
 
-extern "C" void rd_exporter_destroy(rd_exporter *e)
+extern "C" void rd_exporter_destroy(rd_exporter *e) try
 {
     if (!e) return;
     {
@@ -630,10 +819,12 @@ extern "C" void rd_exporter_destroy(rd_exporter *e)
     delete[] e->slots;
     delete e;
 }
+RD_CATCH_VOID(rd_exporter_destroy)
 
 extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t math_mode, uint32_t n_slots,
-                                  rd_exporter **out)
+                                  rd_exporter **out) try
 {
+    RD_ENTRY(rd_exporter_create);
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!w || !h || !n_slots || n_slots > 64) return rd_fail(RD_ERR_INVALID_ARG, "bad frame size or slot count");
@@ -653,6 +844,9 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
     if (rc) return rc;
     rd_exporter *e = new (std::nothrow) rd_exporter;
     if (!e) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    struct undo { void operator()(rd_exporter *q) const { rd_exporter_destroy(q); } };
+    std::unique_ptr<rd_exporter, undo> hold(e);                  // whatever fails or throws below: what exists is released
+    RD_FAULT_POINT("exporter.slots");
     e->device = device; e->w = w; e->h = h; e->fmt = fmt; e->math_mode = math_mode; e->n_slots = n_slots;
     e->bytes = (size_t)w * h * bpp;
     e->cfg.n_cu = n_cu;
@@ -666,14 +860,12 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].kernel_done, hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->slots[i].copy_done, hipEventDisableTiming);
     }
-    if (err != hipSuccess) {
-        int code = rd_fail(err == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "exporter setup failed: %s", hipGetErrorString(err));
-        rd_exporter_destroy(e);
-        return code;
-    }
-    *out = e;
+    if (err != hipSuccess)
+        return rd_fail(err == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "exporter setup failed: %s", hipGetErrorString(err));
+    *out = hold.release();
     return RD_OK;
 }
+RD_CATCH_INT(rd_exporter_create)
 
 // cfa_host != nullptr: the frame's CFA plane comes from HOST memory (rd_exporter_submit_host) and travels through the slot's
 // own HBM plane on a third stream, so the upload of frame i+1 runs under the kernel and the read-back of frame i (PCIe is
@@ -734,21 +926,26 @@ static int rd_exporter_submit_impl(rd_exporter *e, const rd_frame *fr, const uin
     return RD_OK;
 }
 
-extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out)
+extern "C" int rd_exporter_submit(rd_exporter *e, const rd_frame *fr, uint32_t *slot_out) try
 {
+    RD_ENTRY(rd_exporter_submit);
     if (!e || !fr || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     if (!fr->cfa_dev || ((uintptr_t)fr->cfa_dev % 4u)) return rd_fail(RD_ERR_INVALID_ARG, "cfa_dev NULL or not 4-byte aligned");
     return rd_exporter_submit_impl(e, fr, nullptr, slot_out);
 }
+RD_CATCH_INT(rd_exporter_submit)
 
-extern "C" int rd_exporter_submit_host(rd_exporter *e, const rd_frame *fr, const uint16_t *cfa_host, uint32_t *slot_out)
+extern "C" int rd_exporter_submit_host(rd_exporter *e, const rd_frame *fr, const uint16_t *cfa_host, uint32_t *slot_out) try
 {
+    RD_ENTRY(rd_exporter_submit_host);
     if (!e || !fr || !cfa_host || !slot_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     return rd_exporter_submit_impl(e, fr, cfa_host, slot_out);
 }
+RD_CATCH_INT(rd_exporter_submit_host)
 
-extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len)
+extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data, size_t *len) try
 {
+    RD_ENTRY(rd_exporter_wait);
     if (!e || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
     rd_devguard g(e->device);
@@ -764,13 +961,16 @@ extern "C" int rd_exporter_wait(rd_exporter *e, uint32_t slot, const void **data
     if (len) *len = e->bytes;
     return RD_OK;
 }
+RD_CATCH_INT(rd_exporter_wait)
 
-extern "C" int rd_exporter_release(rd_exporter *e, uint32_t slot)
+extern "C" int rd_exporter_release(rd_exporter *e, uint32_t slot) try
 {
+    RD_ENTRY(rd_exporter_release);
     if (!e) return rd_fail(RD_ERR_INVALID_ARG, "NULL exporter");
     if (slot >= e->n_slots) return rd_fail(RD_ERR_INVALID_ARG, "slot %u out of range", slot);
     std::lock_guard<std::mutex> lk(e->mu);
     e->slots[slot].busy = false;
     return RD_OK;
 }
+RD_CATCH_INT(rd_exporter_release)
 

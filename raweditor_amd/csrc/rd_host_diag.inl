@@ -27,8 +27,9 @@ __global__ void __launch_bounds__(256) rd_q8_sweep(uint32_t base, rd_q8_stats *s
     }
 }
 
-extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks, float *max_dist)
+extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks, float *max_dist) try
 {
+    RD_ENTRY(rd_selftest_q8);
     int rc = rd_check_device(device, nullptr);
     if (rc) return rc;
     rd_devguard g(device);
@@ -49,6 +50,7 @@ extern "C" int rd_selftest_q8(int device, uint64_t *mismatches, uint32_t *first_
     if (max_dist) *max_dist = rd_u2f(st.max_dist_bits);
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_q8)
 
 // The export kernel's threshold table (rd_q8_lut_bits) against the pinned evaluation, same sweep: the table in LDS, as there.
 __global__ void __launch_bounds__(256) rd_q8_lut_sweep(uint32_t base, rd_q8_stats *st, uint8_t *codes)
@@ -65,8 +67,9 @@ __global__ void __launch_bounds__(256) rd_q8_lut_sweep(uint32_t base, rd_q8_stat
     if (fast != exact) { atomicAdd(&st->mismatches, 1ull); atomicMin(&st->first_bad, base + i); }
 }
 
-extern "C" int rd_selftest_q8_lut(int device, uint64_t *mismatches, uint32_t *first_bad)
+extern "C" int rd_selftest_q8_lut(int device, uint64_t *mismatches, uint32_t *first_bad) try
 {
+    RD_ENTRY(rd_selftest_q8_lut);
     int rc = rd_check_device(device, nullptr);
     if (rc) return rc;
     rd_devguard g(device);
@@ -87,9 +90,11 @@ extern "C" int rd_selftest_q8_lut(int device, uint64_t *mismatches, uint32_t *fi
     if (first_bad) *first_bad = st.first_bad;
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_q8_lut)
 
-extern "C" int rd_selftest_q8_lut_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
+extern "C" int rd_selftest_q8_lut_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst) try
 {
+    RD_ENTRY(rd_selftest_q8_lut_codes);
     if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
         return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_q8_lut_codes: n must be a non-zero multiple of 256 inside the 2^32 encodings");
     int rc = rd_check_device(device, nullptr);
@@ -107,14 +112,17 @@ extern "C" int rd_selftest_q8_lut_codes(int device, uint32_t first_encoding, uin
     if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_lut_codes: %s", hipGetErrorString(e));
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_q8_lut_codes)
 
 // No device needed: the table itself (RD_Q8_LUT_WORDS words), for host-side checks of its construction.
-extern "C" int rd_q8_lut_table(uint32_t *dst, size_t cap_words)
+extern "C" int rd_q8_lut_table(uint32_t *dst, size_t cap_words) try
 {
+    RD_ENTRY(rd_q8_lut_table);
     if (!dst || cap_words < RD_Q8_LUT_WORDS) return rd_fail(RD_ERR_INVALID_ARG, "rd_q8_lut_table: need room for %u words", RD_Q8_LUT_WORDS);
     rd_q8_lut_build(dst);
     return (int)RD_Q8_LUT_WORDS;
 }
+RD_CATCH_INT(rd_q8_lut_table)
 
 // The same for the binary16 surface's shortcut (rd_f16_gamma): halves and, with the histogram, codes.
 __global__ void __launch_bounds__(256) rd_f16_sweep(uint32_t base, rd_q8_stats *st, uint16_t *halves)
@@ -138,8 +146,9 @@ __global__ void __launch_bounds__(256) rd_f16_sweep(uint32_t base, rd_q8_stats *
     }
 }
 
-extern "C" int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks)
+extern "C" int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *fallbacks) try
 {
+    RD_ENTRY(rd_selftest_f16);
     int rc = rd_check_device(device, nullptr);
     if (rc) return rc;
     rd_devguard g(device);
@@ -159,9 +168,11 @@ extern "C" int rd_selftest_f16(int device, uint64_t *mismatches, uint32_t *first
     if (fallbacks) *fallbacks = st.fallbacks;
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_f16)
 
-extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst)
+extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint32_t n, uint16_t *dst) try
 {
+    RD_ENTRY(rd_selftest_f16_halves);
     if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
         return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_f16_halves: n must be a non-zero multiple of 256 inside the 2^32 encodings");
     int rc = rd_check_device(device, nullptr);
@@ -177,6 +188,7 @@ extern "C" int rd_selftest_f16_halves(int device, uint32_t first_encoding, uint3
     if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16_halves: %s", hipGetErrorString(e));
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_f16_halves)
 
 // The export kernel's two-level tables for the f16 surface (rd_f16_lut_lookup + the pinned evaluation for the lanes it sends
 // there) against the pinned function, same sweep: tables in LDS, as there.  dst (optional): (half | code << 16) per encoding.
@@ -204,8 +216,9 @@ __global__ void __launch_bounds__(256) rd_f16_lut_sweep(uint32_t base, rd_q8_sta
     if (pinned) atomicAdd(&st->fallbacks, 1ull);
 }
 
-extern "C" int rd_selftest_f16_lut(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *pinned)
+extern "C" int rd_selftest_f16_lut(int device, uint64_t *mismatches, uint32_t *first_bad, uint64_t *pinned) try
 {
+    RD_ENTRY(rd_selftest_f16_lut);
     int rc = rd_check_device(device, nullptr);
     if (rc) return rc;
     rd_devguard g(device);
@@ -227,9 +240,11 @@ extern "C" int rd_selftest_f16_lut(int device, uint64_t *mismatches, uint32_t *f
     if (pinned) *pinned = st.fallbacks;
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_f16_lut)
 
-extern "C" int rd_selftest_f16_lut_values(int device, uint32_t first_encoding, uint32_t n, uint32_t *dst)
+extern "C" int rd_selftest_f16_lut_values(int device, uint32_t first_encoding, uint32_t n, uint32_t *dst) try
 {
+    RD_ENTRY(rd_selftest_f16_lut_values);
     if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
         return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_f16_lut_values: n must be a non-zero multiple of 256 inside the 2^32 encodings");
     int rc = rd_check_device(device, nullptr);
@@ -247,20 +262,24 @@ extern "C" int rd_selftest_f16_lut_values(int device, uint32_t first_encoding, u
     if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_f16_lut_values: %s", hipGetErrorString(e));
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_f16_lut_values)
 
 // No device needed: the two tables themselves (fine: RD_F16_LUT_NF u16; coarse: RD_F16_LUT_NC {E, C} pairs), for host-side checks
 // of their construction.  Returns the builder's verdict (0: the shape the lookup assumes) or a negative status.
-extern "C" int rd_f16_lut_tables(uint16_t *fine, size_t cap_fine, uint32_t *coarse, size_t cap_coarse_words)
+extern "C" int rd_f16_lut_tables(uint16_t *fine, size_t cap_fine, uint32_t *coarse, size_t cap_coarse_words) try
 {
+    RD_ENTRY(rd_f16_lut_tables);
     if (!fine || !coarse || cap_fine < RD_F16_LUT_NF + 1u || cap_coarse_words < RD_F16_LUT_NC * 2u)
         return rd_fail(RD_ERR_INVALID_ARG, "rd_f16_lut_tables: need room for %u u16 and %u words", RD_F16_LUT_NF + 1u, RD_F16_LUT_NC * 2u);
     const int rc = rd_f16_lut_build(fine, coarse);
     if (rc) return rd_fail(RD_ERR_UNSUPPORTED, "the binary16 threshold tables cannot be built from this gamma (check %d)", rc);
     return RD_OK;
 }
+RD_CATCH_INT(rd_f16_lut_tables)
 
-extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst)
+extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_t n, uint8_t *dst) try
 {
+    RD_ENTRY(rd_selftest_q8_codes);
     if (!dst || !n || (n & 255u) || (uint64_t)first_encoding + n > (1ull << 32))
         return rd_fail(RD_ERR_INVALID_ARG, "rd_selftest_q8_codes: n must be a non-zero multiple of 256 inside the 2^32 encodings");
     int rc = rd_check_device(device, nullptr);
@@ -276,6 +295,7 @@ extern "C" int rd_selftest_q8_codes(int device, uint32_t first_encoding, uint32_
     if (e != hipSuccess) return rd_fail(RD_ERR_HIP, "rd_selftest_q8_codes: %s", hipGetErrorString(e));
     return RD_OK;
 }
+RD_CATCH_INT(rd_selftest_q8_codes)
 
 // ------------------------------------------------------------------------------------------------
 // measurement aid: the streaming ceilings of THIS device, now (bench.py: roofline.box_copy_GBps / box_fill_GBps)
@@ -324,22 +344,45 @@ __global__ void __launch_bounds__(1024) rd_probe_read(const rd_f4 *__restrict__ 
 }
 
 extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *copy_GBps, double *fill_GBps, double *read_GBps,
-                              double *memset_GBps)
+                              double *memset_GBps) try
 {
-    if (bytes < ((size_t)64 << 20) || !reps || reps > 64) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need >= 64 MiB and 1..64 repetitions");
+    RD_ENTRY(rd_measure_hbm);
+    if (!reps || reps > 64) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need 1..64 repetitions");
+    // copy: 4096 x 16 waves, fill / read: 2048 x 16 waves.  Every wave of EVERY grid must own a whole number of 8-KiB steps
+    // (the kernels have no tail handling: a wave whose share is not a multiple of a step runs into its neighbour's range, the
+    // last one past the allocation).  So the size is rounded down to whole steps of the LARGER grid -- 4096 x 16 x 8 KiB =
+    // 512 MiB per buffer -- which gives the smaller grid's waves an even number of steps; anything below one such unit is refused.
+    const uint32_t blocks[3] = { 4096u, 2048u, 2048u };
+    const size_t step = 64u * RD_PROBE_U;                                        // float4 per wave and step
+    const size_t unit = (size_t)blocks[0] * 16u * step;                           // float4 per step of the whole copy grid
+    const size_t n = bytes / sizeof(rd_f4) / unit * unit;                         // float4 actually moved
+    if (!n) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_hbm: need at least %zu MiB (one 8-KiB step for each of %u waves)",
+                           (unit * sizeof(rd_f4)) >> 20, blocks[0] * 16u);
     int rc = rd_check_device(device, nullptr);
     if (rc) return rc;
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    // copy: 4096 x 16 waves, fill / read: 2048 x 16 waves; every wave owns a whole number of 8-KiB steps
-    const uint32_t blocks[3] = { 4096u, 2048u, 2048u };
-    const size_t step = 64u * RD_PROBE_U;                                        // float4 per wave and step
-    const size_t per_wave_max = bytes / sizeof(rd_f4) / (2048u * 16u) / step * step;
-    const size_t n = per_wave_max * 2048u * 16u;                                  // float4 actually moved (both grids divide it)
-    void *a = nullptr, *b = nullptr;
-    float *sink = nullptr;
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct res {                                                 // released on every path, an exception included
+        void *a = nullptr, *b = nullptr;
+        float *sink = nullptr;
+        hipStream_t s = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~res()
+        {
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            if (sink) (void)hipFree(sink);
+        }
+    } r_;
+    void *&a = r_.a, *&b = r_.b;
+    float *&sink = r_.sink;
+    hipStream_t &s = r_.s;
+    hipEvent_t &e0 = r_.e0, &e1 = r_.e1;
+    std::vector<float> ms;
+    ms.reserve(reps + 1u);
     hipError_t e = hipMalloc(&a, n * sizeof(rd_f4));
     if (e == hipSuccess) e = hipMalloc(&b, n * sizeof(rd_f4));
     if (e == hipSuccess) e = hipMalloc((void **)&sink, sizeof(float));
@@ -350,8 +393,8 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
     if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(rd_f4), s);
     double out[4] = { 0.0, 0.0, 0.0, 0.0 };
     for (int which = 0; which < 4 && e == hipSuccess; ++which) {
-        std::vector<float> ms;
-        const size_t per_wave = which < 3 ? n / ((size_t)blocks[which] * 16u) : 0;
+        ms.clear();
+        const size_t per_wave = which < 3 ? n / ((size_t)blocks[which] * 16u) : 0;          // a multiple of `step` for all three grids
         for (uint32_t r = 0; r < reps + 1u && e == hipSuccess; ++r) {             // the first launch warms up
             e = hipEventRecord(e0, s);
             if (which == 0) hipLaunchKernelGGL(rd_probe_copy, dim3(blocks[0]), dim3(1024), 0, s, (const rd_f4 *)a, (rd_f4 *)b, per_wave);
@@ -371,12 +414,6 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
             out[which] = (which == 0 ? 2.0 : 1.0) * (double)(n * sizeof(rd_f4)) / (med * 1e-3) / 1e9;
         }
     }
-    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    if (sink) (void)hipFree(sink);
     if (e != hipSuccess) return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "rd_measure_hbm: %s", hipGetErrorString(e));
     if (copy_GBps) *copy_GBps = out[0];
     if (fill_GBps) *fill_GBps = out[1];
@@ -384,6 +421,7 @@ extern "C" int rd_measure_hbm(int device, size_t bytes, uint32_t reps, double *c
     if (memset_GBps) *memset_GBps = out[3];
     return RD_OK;
 }
+RD_CATCH_INT(rd_measure_hbm)
 
 // What one full-rate VALU wave-instruction costs a SIMD on THIS device right now: 512 x 1024 threads (8 waves per SIMD, as
 // the export kernel runs), eight independent chains per lane of alternating v_mul_f32 / v_add_f32 -- the two-operand forms
@@ -411,8 +449,9 @@ __global__ void __launch_bounds__(1024) rd_probe_valu(float *out, float a, float
     if (s == 1234.5678f) out[0] = s;
 }
 
-extern "C" int rd_measure_valu(int device, double *ns_per_full_rate_instruction)
+extern "C" int rd_measure_valu(int device, double *ns_per_full_rate_instruction) try
 {
+    RD_ENTRY(rd_measure_valu);
     if (!ns_per_full_rate_instruction) return rd_fail(RD_ERR_INVALID_ARG, "rd_measure_valu: NULL argument");
     int n_cu = 0;
     int rc = rd_check_device(device, &n_cu);
@@ -448,4 +487,5 @@ extern "C" int rd_measure_valu(int device, double *ns_per_full_rate_instruction)
     *ns_per_full_rate_instruction = ms.front() * 1e6 / per_simd;      // the fastest of five: the clock the part reaches under pure VALU load
     return RD_OK;
 }
+RD_CATCH_INT(rd_measure_valu)
 

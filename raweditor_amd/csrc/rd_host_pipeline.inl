@@ -18,6 +18,7 @@
 #define RD_STAGE_SLOTS 3                         // pinned staging slots of RD_STAGE_BYTES each (pageable destinations)
 #define RD_STAGE_BYTES ((size_t)8 << 20)
 #define RD_BAND_MIN_BYTES ((size_t)16 << 20)     // smaller surfaces: one launch, one copy
+#define RD_LENT_MAX 4                            // page-locked surfaces out on loan at a time (rd_render_full_res_borrow)
 
 struct rd_lane {
     hipStream_t compute = nullptr, copy = nullptr;
@@ -115,9 +116,10 @@ static int rd_lane_acquire(rd_pipeline *p, size_t need, rd_lane **out)
         rd_lane *l = fit;
         if (!l && any && (p->lanes.size() >= RD_LANES_MAX || need <= RD_BAND_MIN_BYTES || any->out_cap == 0)) l = any;
         if (!l && p->lanes.size() < RD_LANES_MAX) {
+            RD_FAULT_POINT("pipeline.lanes");
             const int rc = rd_lane_new(&l);
             if (rc) return rc;
-            p->lanes.push_back(l);
+            p->lanes.push_back(l);                               // capacity reserved by rd_pipeline_new: cannot throw
         }
         if (!l && any) l = any;
         if (l) { l->busy = true; *out = l; return RD_OK; }
@@ -162,9 +164,18 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
 
     rc = rd_q8_lut_ensure(device);
+    // (the binary16 tables too, here and not at the first RGBA-f16 render: building them takes ~40 ms of host time once per
+    // process and the upload is a synchronous null-stream copy -- neither belongs on rd_render_device, which promises an
+    // asynchronous enqueue on the caller's stream and may run under stream capture)
+    if (rc == RD_OK) rc = rd_f16_lut_ensure(device);
     if (rc) return rc;
     rd_pipeline *p = new (std::nothrow) rd_pipeline;
     if (!p) return rd_fail(RD_ERR_OOM, "host allocation failed");
+    struct undo { void operator()(rd_pipeline *q) const { rd_pipeline_destroy(q); } };
+    std::unique_ptr<rd_pipeline, undo> hold(p);                  // whatever throws below: the half-built pipeline is destroyed
+    RD_FAULT_POINT("pipeline.lanes");
+    p->lanes.reserve(RD_LANES_MAX);
+    p->lents.reserve(RD_LENT_MAX);
     p->device = device;
     p->cfg.n_cu = n_cu;
     p->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
@@ -178,7 +189,7 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
 
     rd_lane *l0 = nullptr;
     rc = rd_lane_new(&l0);
-    if (rc) { rd_pipeline_destroy(p); return rc; }
+    if (rc) return rc;
     p->lanes.push_back(l0);
     p->stream = l0->compute;
     hipError_t e = hipSuccess;
@@ -192,30 +203,31 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
             e = hipMemcpy(d, cfa, (size_t)w * h * sizeof(uint16_t), hipMemcpyHostToDevice);
         }
     }
-    if (e != hipSuccess) {
-        int code = rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "pipeline setup failed: %s", hipGetErrorString(e));
-        rd_pipeline_destroy(p);
-        return code;
-    }
-    *out = p;
+    if (e != hipSuccess)
+        return rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "pipeline setup failed: %s", hipGetErrorString(e));
+    *out = hold.release();
     return RD_OK;
 }
 
 extern "C" int rd_pipeline_create(int device, int64_t image_id, const uint16_t *cfa, uint32_t w, uint32_t h,
                                   const rd_edit_params *params, const float wb[4], const float cm[9],
-                                  rd_pipeline **out)
+                                  rd_pipeline **out) try
 {
+    RD_ENTRY(rd_pipeline_create);
     return rd_pipeline_new(device, image_id, cfa, false, w, h, params, wb, cm, out);
 }
+RD_CATCH_INT(rd_pipeline_create)
 
 extern "C" int rd_pipeline_create_from_device(int device, int64_t image_id, const uint16_t *cfa_dev, uint32_t w,
                                               uint32_t h, const rd_edit_params *params, const float wb[4],
-                                              const float cm[9], rd_pipeline **out)
+                                              const float cm[9], rd_pipeline **out) try
 {
+    RD_ENTRY(rd_pipeline_create_from_device);
     return rd_pipeline_new(device, image_id, cfa_dev, true, w, h, params, wb, cm, out);
 }
+RD_CATCH_INT(rd_pipeline_create_from_device)
 
-extern "C" void rd_pipeline_destroy(rd_pipeline *p)
+extern "C" void rd_pipeline_destroy(rd_pipeline *p) try
 {
     if (!p) return;
     {
@@ -232,54 +244,67 @@ extern "C" void rd_pipeline_destroy(rd_pipeline *p)
     }
     delete p;
 }
+RD_CATCH_VOID(rd_pipeline_destroy)
 
-extern "C" int rd_pipeline_info(const rd_pipeline *p, rd_info *out)
+extern "C" int rd_pipeline_info(const rd_pipeline *p, rd_info *out) try
 {
+    RD_ENTRY(rd_pipeline_info);
     if (!p || !out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     *out = p->info;
     return RD_OK;
 }
+RD_CATCH_INT(rd_pipeline_info)
 
-extern "C" int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t bl)
+extern "C" int rd_pipeline_set_black_level(rd_pipeline *p, uint32_t bl) try
 {
+    RD_ENTRY(rd_pipeline_set_black_level);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     std::lock_guard<std::mutex> lk(p->mu);
     p->black_level = bl;
     return RD_OK;
 }
+RD_CATCH_INT(rd_pipeline_set_black_level)
 
-extern "C" int rd_pipeline_set_matrix_layout(rd_pipeline *p, uint32_t layout)
+extern "C" int rd_pipeline_set_matrix_layout(rd_pipeline *p, uint32_t layout) try
 {
+    RD_ENTRY(rd_pipeline_set_matrix_layout);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     if (layout != RD_MATRIX_REFERENCE && layout != RD_MATRIX_ROW_MAJOR) return rd_fail(RD_ERR_INVALID_ARG, "unknown matrix layout %u", layout);
     std::lock_guard<std::mutex> lk(p->mu);
     p->matrix_layout = layout;
     return RD_OK;
 }
+RD_CATCH_INT(rd_pipeline_set_matrix_layout)
 
-extern "C" int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t mode)
+extern "C" int rd_pipeline_set_math_mode(rd_pipeline *p, uint32_t mode) try
 {
+    RD_ENTRY(rd_pipeline_set_math_mode);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     if (mode != RD_MATH_STRICT && mode != RD_MATH_CONTRACTED) return rd_fail(RD_ERR_INVALID_ARG, "unknown math mode %u", mode);
     std::lock_guard<std::mutex> lk(p->mu);
     p->math_mode = mode;
     return RD_OK;
 }
+RD_CATCH_INT(rd_pipeline_set_math_mode)
 
 extern "C" int rd_update_uniforms_with_zoom(rd_pipeline *p, const rd_edit_params *params, float zoom, float pan_x,
-                                            float pan_y)
+                                            float pan_y) try
 {
+    RD_ENTRY(rd_update_uniforms_with_zoom);
     if (!p || !params) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(p->mu);
     p->params = *params;     // wb / matrix are preserved, as in pipeline.rs:375-381
     p->zoom = zoom; p->pan_x = pan_x; p->pan_y = pan_y;
     return RD_OK;
 }
+RD_CATCH_INT(rd_update_uniforms_with_zoom)
 
-extern "C" int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params)
+extern "C" int rd_update_uniforms(rd_pipeline *p, const rd_edit_params *params) try
 {
+    RD_ENTRY(rd_update_uniforms);
     return rd_update_uniforms_with_zoom(p, params, 1.0f, 0.0f, 0.0f);   // pipeline.rs:367-369
 }
+RD_CATCH_INT(rd_update_uniforms)
 
 // The uniforms as they stand now: the only thing a render reads under the pipeline's mutex.  (The reference's export
 // re-uses whatever view() last wrote, main.rs:1515 vs :1754; a snapshot keeps that and removes the tear a concurrent
@@ -313,10 +338,6 @@ static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, u
     const uint32_t W = p->info.width, H = p->info.height;
     const bool quads = rd_pipeline_uses_quads(p, sh, tw, th, fmt);
     if (!unit1) unit1 = H / 2u + 1u;
-    if (quads && fmt == RD_FMT_RGBA_F16) {                       // the export kernel's binary16 tables: built on first use
-        const int rc = rd_f16_lut_ensure(p->device);
-        if (rc) return rc;
-    }
     uint32_t blocks = 0;
     const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
@@ -369,14 +390,16 @@ static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, u
 }
 
 extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst_dev,
-                                uint32_t *hist_dev, void *stream)
+                                uint32_t *hist_dev, void *stream) try
 {
+    RD_ENTRY(rd_render_device);
     if (!p || !dst_dev) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     rd_devguard g(p->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
     const rd_shot sh = rd_pipeline_snapshot(p);
     return rd_pipeline_enqueue(p, sh, out_w, out_h, fmt, dst_dev, hist_dev, (hipStream_t)stream);
 }
+RD_CATCH_INT(rd_render_device)
 
 // Is [ptr, ptr + n) page-locked host memory the DMA engines can write (hipHostMalloc / rd_host_alloc / hipHostRegister)?
 enum { RD_MEM_PAGEABLE = 0, RD_MEM_PINNED = 1, RD_MEM_DEVICE = 2 };
@@ -391,6 +414,17 @@ static int rd_host_memory_kind(const void *ptr, size_t n)
         if (e != hipSuccess) { (void)hipGetLastError(); kind = RD_MEM_PAGEABLE; continue; }    // plain malloc memory: "invalid value"
         if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return RD_MEM_DEVICE;
         if (a.type != hipMemoryTypeHost) kind = RD_MEM_PAGEABLE;       // unregistered / managed: staged
+    }
+    if (kind == RD_MEM_PINNED && n > 1) {
+        // Both ENDS are page-locked; the middle must be too before a DMA engine is pointed at the range: two registrations
+        // with a gap between them, or a buffer that outgrew its registered window, would pass the test above.  One
+        // allocation (or registration) must cover [ptr, ptr + n); if the runtime cannot say, the range is staged.
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        const hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
+        if (e != hipSuccess) { (void)hipGetLastError(); return RD_MEM_PAGEABLE; }
+        const uintptr_t lo = (uintptr_t)base, hi = lo + size, p0 = (uintptr_t)ptr;
+        if (!(p0 >= lo && p0 + n <= hi)) return RD_MEM_PAGEABLE;
     }
     return kind;
 }
@@ -542,8 +576,9 @@ static int rd_render_full_host(rd_pipeline *p, rd_lane *l, const rd_shot &sh, ui
 }
 
 extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_t fmt, void *dst, size_t dst_len,
-                         uint32_t hist[768])
+                         uint32_t hist[768]) try
 {
+    RD_ENTRY(rd_render);
     if (!p || !dst) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     const size_t bpp = rd_format_bytes_per_pixel(fmt);
     if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
@@ -573,26 +608,31 @@ extern "C" int rd_render(rd_pipeline *p, uint32_t out_w, uint32_t out_h, uint32_
     }
     return RD_OK;
 }
+RD_CATCH_INT(rd_render)
 
-extern "C" int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
+extern "C" int rd_render_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len) try
 {
+    RD_ENTRY(rd_render_to_bytes);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     return rd_render(p, p->info.preview_width, p->info.preview_height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
 }
+RD_CATCH_INT(rd_render_to_bytes)
 
-extern "C" int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
+extern "C" int rd_render_full_res_to_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len) try
 {
+    RD_ENTRY(rd_render_full_res_to_bytes);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     return rd_render(p, p->info.width, p->info.height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
 }
+RD_CATCH_INT(rd_render_full_res_to_bytes)
 
 // render_full_res_to_bytes without the caller's allocation: the surface is rendered into page-locked memory the PIPELINE owns
 // (allocated on first use, reused afterwards: pinning 96.6 MB costs milliseconds, a fresh pageable Vec its page faults) and
 // lent to the caller until rd_surface_release.  What export_image_async needs -- a &[u8] for image::save_buffer
 // (main.rs:1765-1791) -- at the price of the PCIe transfer.  Up to RD_LENT_MAX surfaces may be out at a time.
-#define RD_LENT_MAX 4
-extern "C" int rd_render_full_res_borrow(rd_pipeline *p, const uint8_t **data, size_t *len)
+extern "C" int rd_render_full_res_borrow(rd_pipeline *p, const uint8_t **data, size_t *len) try
 {
+    RD_ENTRY(rd_render_full_res_borrow);
     if (!p || !data) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     *data = nullptr;
     const size_t need = (size_t)p->info.width * p->info.height * 4u;
@@ -622,9 +662,11 @@ extern "C" int rd_render_full_res_borrow(rd_pipeline *p, const uint8_t **data, s
     if (len) *len = need;
     return RD_OK;
 }
+RD_CATCH_INT(rd_render_full_res_borrow)
 
-extern "C" int rd_surface_release(rd_pipeline *p, const uint8_t *data)
+extern "C" int rd_surface_release(rd_pipeline *p, const uint8_t *data) try
 {
+    RD_ENTRY(rd_surface_release);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     if (!data) return RD_OK;
     std::lock_guard<std::mutex> lk(p->lent_mu);
@@ -636,15 +678,19 @@ extern "C" int rd_surface_release(rd_pipeline *p, const uint8_t *data)
         }
     return rd_fail(RD_ERR_INVALID_ARG, "not a surface borrowed from this pipeline");
 }
+RD_CATCH_INT(rd_surface_release)
 
-extern "C" int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len)
+extern "C" int rd_render_to_histogram_bytes(rd_pipeline *p, uint8_t *dst, size_t dst_len) try
 {
+    RD_ENTRY(rd_render_to_histogram_bytes);
     if (!p) return rd_fail(RD_ERR_INVALID_ARG, "NULL pipeline");
     return rd_render(p, p->info.histogram_width, p->info.histogram_height, RD_FMT_RGBA_U8, dst, dst_len, nullptr);
 }
+RD_CATCH_INT(rd_render_to_histogram_bytes)
 
-extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_t rgba_len, uint32_t hist[768])
+extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_t rgba_len, uint32_t hist[768]) try
 {
+    RD_ENTRY(rd_calculate_histogram);
     if (!p || !hist || (!rgba && rgba_len)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
     if (rgba_len % 4) return rd_fail(RD_ERR_INVALID_ARG, "rgba_len %zu is not a multiple of 4", rgba_len);
     const size_t npx = rgba_len / 4;
@@ -671,11 +717,13 @@ extern "C" int rd_calculate_histogram(rd_pipeline *p, const uint8_t *rgba, size_
     RD_HIP(hipStreamSynchronize(ln->compute));
     return RD_OK;
 }
+RD_CATCH_INT(rd_calculate_histogram)
 
 // Page-locked host memory for render destinations (and sources): what a host that wants the direct-DMA path allocates
 // its surface buffer from.  Any thread, any time; rd_host_free(NULL) is a no-op.
-extern "C" int rd_host_alloc(int device, size_t bytes, void **out)
+extern "C" int rd_host_alloc(int device, size_t bytes, void **out) try
 {
+    RD_ENTRY(rd_host_alloc);
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     rd_devguard g(device);
@@ -683,13 +731,16 @@ extern "C" int rd_host_alloc(int device, size_t bytes, void **out)
     RD_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
     return RD_OK;
 }
+RD_CATCH_INT(rd_host_alloc)
 
-extern "C" int rd_host_free(int device, void *ptr)
+extern "C" int rd_host_free(int device, void *ptr) try
 {
+    RD_ENTRY(rd_host_free);
     if (!ptr) return RD_OK;
     rd_devguard g(device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
     RD_HIP(hipHostFree(ptr));
     return RD_OK;
 }
+RD_CATCH_INT(rd_host_free)
 

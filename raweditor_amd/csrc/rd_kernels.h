@@ -1637,6 +1637,13 @@ __global__ void __launch_bounds__(RD_FOLD_THREADS) rd_reduce_slab32(uint32_t *__
     if (threadIdx.x < 32u) out32[blockIdx.x * 32u + threadIdx.x] = tot;
 }
 
+// dst[0..768) = src[0..768): a device's folded histogram into page-locked host memory (rd_node_batch_histogram_enqueue).
+__global__ void __launch_bounds__(768) rd_copy_hist64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst)
+{
+    dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+}
+
 // out64[bin] = sum over workgroups of slab64[wg][bin]; the slab is zeroed for the next batch.
 __global__ void __launch_bounds__(RD_FOLD_THREADS) rd_reduce_slab64(unsigned long long *__restrict__ slab64, uint32_t nblocks,
                                                         unsigned long long *__restrict__ out64)

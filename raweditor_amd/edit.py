@@ -28,6 +28,37 @@ def _f32(x) -> float:
     return float(np.float32(x))
 
 
+def ryu_f32(v) -> str:
+    """The text serde_json writes for a finite f32 (EditParams::to_json, edit.rs:105-107): the `ryu` crate's format32 -- the
+    shortest decimal digits that round-trip, laid out by the decimal exponent: with `digits` x 10^k and kk = len(digits) + k,
+      0 <= k and kk <= 13   ->  digits, k zeros, ".0"         (1.0, 16777216.0, 9999999827968.0)
+      0 <  kk <= 13         ->  point inside the digits       (12.34)
+      -6 < kk <= 0          ->  "0.", -kk zeros, digits       (0.001234, 0.000001)
+      otherwise             ->  d[.ddd]e<exp>, no '+', no padding   (1e-7, 1.5e-7, 1e13, 3.4028235e38)
+    and a sign for negative values including -0.0.  (For f64 the two 13s are 16s; EditParams' fields are f32.)"""
+    v = np.float32(v)
+    if v == 0:
+        return "-0.0" if np.signbit(v) else "0.0"
+    s = np.format_float_scientific(v, unique=True, trim="-", exp_digits=1)        # '1.5e-07' style pieces: digits + exponent
+    sign = "-" if s.startswith("-") else ""
+    mant, exp = s.lstrip("-").split("e")
+    digits = mant.replace(".", "")
+    e10 = int(exp)
+    n = len(digits)
+    k, kk = e10 - (n - 1), e10 + 1
+    if 0 <= k and kk <= 13:
+        body = digits + "0" * k + ".0"
+    elif 0 < kk <= 13:
+        body = digits[:kk] + "." + digits[kk:]
+    elif -6 < kk <= 0:
+        body = "0." + "0" * (-kk) + digits
+    elif n == 1:
+        body = f"{digits}e{kk - 1}"
+    else:
+        body = f"{digits[0]}.{digits[1:]}e{kk - 1}"
+    return sign + body
+
+
 @dataclasses.dataclass
 class EditParams:
     exposure: float = 0.0
@@ -53,11 +84,11 @@ class EditParams:
     def new(cls) -> "EditParams":            # edit.rs:100-102
         return cls.default()
 
-    def to_json(self) -> str:                 # edit.rs:105-107 (serde field order, shortest f32 repr)
+    def to_json(self) -> str:                 # edit.rs:105-107: serde's field order, ryu's text for every f32 (ryu_f32 above)
         def num(v: float) -> str:
             if not np.isfinite(v):
                 return "null"                  # serde_json writes non-finite floats as null
-            return np.format_float_positional(np.float32(v), unique=True, trim="0")
+            return ryu_f32(v)
         return "{" + ",".join(f'"{f}":{num(getattr(self, f))}' for f in FIELDS) + "}"
 
     @classmethod

@@ -32,6 +32,21 @@ static void test_serialization()                  // edit.rs:135-150
     bool threw = false;
     try { rawdev::EditParams::from_json("{\"exposure\":1.0}"); } catch (const rawdev::Error &) { threw = true; }
     EXPECT(threw);                                 // serde: missing field
+    // serde_json writes an f32 with ryu: exponent form below 1e-6 and from 1e13 on, "-0.0", no '+' and no padding
+    const struct { float v; const char *text; } ryu[] = {
+        { 1e-7f, "1e-7" }, { 1e20f, "1e20" }, { -0.0f, "-0.0" }, { 0.0f, "0.0" }, { 0.3f, "0.3" }, { 1.0f, "1.0" }, { 1234567.0f, "1234567.0" },
+        { 1e13f, "1e13" }, { 1e12f, "1000000000000.0" }, { 1.5e-7f, "1.5e-7" }, { 16777216.0f, "16777216.0" }, { 1e-5f, "0.00001" },
+        { 1e-6f, "0.000001" }, { 9.9e-7f, "9.9e-7" }, { 12.34f, "12.34" }, { 3.4028235e38f, "3.4028235e38" }, { -2.5f, "-2.5" },
+        { 0.001234f, "0.001234" }, { 1.17549435e-38f, "1.1754944e-38" }, { 1e-45f, "1e-45" }, { 123456.79f, "123456.79" }, { 100.0f, "100.0" } };
+    for (const auto &c : ryu) {
+        const std::string got = rawdev::EditParams::ryu_f32(c.v);
+        if (got != c.text) std::printf("ryu_f32(%a) = %s, expected %s\n", (double)c.v, got.c_str(), c.text);
+        EXPECT(got == c.text);
+    }
+    rawdev::EditParams q;
+    q.exposure = 1e-7f; q.contrast = 1e20f; q.tint = -0.0f;
+    EXPECT(q.to_json().find("{\"exposure\":1e-7,\"contrast\":1e20,") == 0 && q.to_json().find("\"tint\":-0.0}") != std::string::npos);
+    EXPECT(rawdev::EditParams::from_json(q.to_json()) == q);
 }
 
 static void test_reset()                          // edit.rs:152-163

@@ -108,3 +108,17 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert r["ranks"][0]["pci_bus_id"] and r["distinct_devices"] == 1 and r["world_size_seen"] == 1
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and "march=native" in cb["build"] and cb["value_portable_O2_build"] > 0
+
+
+def test_measure_hbm_sizes(gpu_lib):
+    """rd_measure_hbm's kernels have no tail handling: the size is rounded down to whole 8-KiB steps of the larger grid
+    (512 MiB units), so 768 MiB -- a size whose copy waves used to run 4 KiB past their range and the last one past the
+    allocation -- measures 512 MiB, and a size below one unit is refused instead of measuring nothing."""
+    ra = gpu_lib
+    for nbytes in (768 << 20, 512 << 20, (1 << 30) + 12345):
+        c, f, r, m = ra.measure_hbm(0, nbytes, 2)
+        assert 1000.0 < c < 8000.0 and 1000.0 < f < 8000.0 and 1000.0 < r < 8000.0 and m > 500.0, (nbytes, c, f, r, m)
+    for nbytes in (64 << 20, 256 << 20, (512 << 20) - 16):
+        with pytest.raises(ra.RawdevError) as ei:
+            ra.measure_hbm(0, nbytes, 2)
+        assert ei.value.code == -1 and "512 MiB" in ei.value.message

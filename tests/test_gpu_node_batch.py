@@ -131,3 +131,40 @@ def test_node_batch_rejects_bad_arguments(gpu_lib):
     with pytest.raises(ra.RawdevError):
         nb.histogram()
     nb.close()
+
+
+def test_histogram_in_two_halves(gpu_lib, refc, monkeypatch):
+    """rd_node_batch_histogram_enqueue / _fetch (round 5): the fold, the reduction and the read-back are enqueued behind the
+    develop call, the next develop call is enqueued behind them without a drain, and fetch hands out the LAST enqueue's sum;
+    N = 1 (no exchange) and the one-GPU rehearsal of N = 3 with the host fold."""
+    ra = gpu_lib
+    h, w, n = 130, 256, 6
+    for devices, env in (([0], None), ([0, 0, 0], "host")):
+        if env:
+            monkeypatch.setenv("RD_NODE_REDUCE", env)
+        cfas, params, exp, exp_hist = _inputs(ra, refc, h, w, n, 7)
+        nb = ra.NodeBatch(devices, w, h, ra.FMT_RGBA_U8, True)
+        d_in = [DevBuf.from_array(c) for c in cfas]
+        d_out = [DevBuf(h * w * 4) for _ in range(n)]
+        frames = ra.BatchExporter.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
+        half = ra.BatchExporter.make_frames([b.ptr for b in d_in[:3]], [b.ptr for b in d_out[:3]], params[:3], WB_DAYLIGHT, CM_TEST)
+        with pytest.raises(ra.RawdevError):
+            nb.histogram_fetch()                                  # nothing enqueued yet
+        for _ in range(3):                                        # three steps queued back to back, no synchronise in between
+            nb.develop(frames)
+            nb.histogram_enqueue()
+        nb.develop(half)
+        nb.histogram_enqueue()
+        got = nb.histogram_fetch().reshape(-1)                    # the last enqueue: the three frames of `half`
+        exp_half = np.zeros(768, np.uint64)
+        for e in exp[:3]:
+            exp_half += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
+        assert np.array_equal(got, exp_half), devices
+        with pytest.raises(ra.RawdevError):
+            nb.histogram_fetch()                                  # one fetch per enqueue
+        nb.develop(frames)
+        assert np.array_equal(nb.histogram().reshape(-1), exp_hist), devices     # the one-call form still synchronises and resets
+        nb.synchronize()
+        for e, o in zip(exp, d_out):
+            assert np.array_equal(o.to_array(np.uint8, (h, w, 4)), refc.pack_u8(e))
+        nb.close()

@@ -516,3 +516,57 @@ def test_dng_subifd_offsets_of_tiff_type_13(tmp_path, rng):
     path.write_bytes(bytes(buf))
     r = ingest.load_dng(str(path))
     assert np.array_equal(r.data.reshape(6, 8), cfa)
+
+
+def test_to_json_is_serde_jsons_text_for_every_magnitude():
+    """EditParams::to_json is serde_json::to_string (edit.rs:105-107), which writes an f32 with ryu's format32: positional
+    between 1e-6 and 1e13, exponent form outside ("1e-7", "1e20": no '+', no padding), "-0.0" for negative zero.  Rows this
+    library writes into `edits.settings_json` must be the bytes the app would have written."""
+    from raweditor_amd import EditParams
+    from raweditor_amd.edit import ryu_f32
+    vectors = [(1e-7, "1e-7"), (1e20, "1e20"), (-0.0, "-0.0"), (0.0, "0.0"), (0.3, "0.3"), (1.0, "1.0"), (1234567.0, "1234567.0"),
+               (1e13, "1e13"), (1e12, "1000000000000.0"), (1.5e-7, "1.5e-7"), (16777216.0, "16777216.0"), (1e-5, "0.00001"),
+               (1e-6, "0.000001"), (9.9e-7, "9.9e-7"), (12.34, "12.34"), (3.4028235e38, "3.4028235e38"), (-2.5, "-2.5"),
+               (0.001234, "0.001234"), (1.17549435e-38, "1.1754944e-38"), (1e-45, "1e-45"), (123456.79, "123456.79"), (100.0, "100.0"),
+               (-1e-7, "-1e-7"), (0.1, "0.1"), (25.0, "25.0"), (0.005, "0.005")]
+    for v, text in vectors:
+        assert ryu_f32(v) == text, (v, ryu_f32(v), text)
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 0x7f800000, 20000, dtype=np.uint32) | (rng.integers(0, 2, 20000, dtype=np.uint32) << 31)
+    for v in bits.view(np.float32):                               # every text reads back as the same float, and is the shortest that does
+        t = ryu_f32(v)
+        assert np.float32(float(t)) == v, (v, t)
+        assert "+" not in t and "E" not in t and (("e" in t) != ("." in t) or "e" in t)
+    p = EditParams(exposure=1e-7, contrast=1e20, tint=-0.0, blacks=0.005)
+    text = p.to_json()
+    assert text == ('{"exposure":1e-7,"contrast":1e20,"highlights":0.0,"shadows":0.0,"whites":1.0,"blacks":0.005,'
+                    '"vibrance":0.0,"saturation":0.0,"temperature":0.0,"tint":-0.0}')
+    q = EditParams.from_json(text)
+    assert q == p and np.signbit(np.float32(q.tint))
+    assert EditParams().to_json() == ('{"exposure":0.0,"contrast":0.0,"highlights":0.0,"shadows":0.0,"whites":1.0,"blacks":0.0,'
+                                      '"vibrance":0.0,"saturation":0.0,"temperature":0.0,"tint":0.0}')      # edit.rs:135-150's shape
+
+
+def test_init_schema_is_the_apps(tmp_path):
+    """library.rs:52-121: a catalog created here has every column and index the app creates (the Phase-28 cache tiers and
+    file_status arrive by ALTER TABLE there, so a second run must not fail either), with the same defaults."""
+    conn = sqlite3.connect(tmp_path / "library.db")
+    catalog.init_schema(conn)
+    catalog.init_schema(conn)                                     # idempotent, like the app's every start
+    cols = {r[1]: (r[2], r[3], r[4], r[5]) for r in conn.execute("PRAGMA table_info(images)")}
+    assert list(cols) == ["id", "path", "filename", "width", "height", "imported_at", "cache_status", "cache_path_thumb",
+                          "cache_path_instant", "cache_path_working", "file_status"]
+    assert cols["cache_status"][2] == "'pending'" and cols["file_status"][2] == "'exists'" and cols["path"][1] == 1
+    assert cols["cache_path_thumb"][0] == "TEXT" and cols["imported_at"] == ("INTEGER", 1, None, 0)
+    ecols = [r[1] for r in conn.execute("PRAGMA table_info(edits)")]
+    assert ecols == ["id", "image_id", "settings_json"]
+    idx = {r[1] for r in conn.execute("PRAGMA index_list(images)")} | {r[1] for r in conn.execute("PRAGMA index_list(edits)")}
+    assert {"idx_images_imported_at", "idx_edits_image_id", "idx_images_cache_status"} <= idx
+    fk = conn.execute("PRAGMA foreign_key_list(edits)").fetchall()
+    assert fk and fk[0][2] == "images" and fk[0][6] == "CASCADE"
+    # the statements the app itself runs against such a file (library.rs: insert_image, update cache paths, file_status)
+    conn.execute("INSERT INTO images (path, filename, width, height, imported_at) VALUES ('/a.nef', 'a.nef', 6016, 4016, 1)")
+    conn.execute("UPDATE images SET cache_path_thumb = '/c/t.jpg', cache_path_instant = '/c/i.jpg', cache_path_working = '/c/w.jpg', "
+                 "cache_status = 'cached' WHERE id = 1")
+    row = conn.execute("SELECT cache_status, file_status, cache_path_working FROM images WHERE id = 1").fetchone()
+    assert row == ("cached", "exists", "/c/w.jpg")

@@ -11,10 +11,16 @@ BENCH="--format $FMT --ring 32 --steps 2 --warmup 1 --frames 32 --no-cpu-baselin
 for lib in lut nolut; do
   for data in uniform gradient; do
     name=${lib}_${data}
-    ( [ $lib = nolut ] && export RAWDEV_LIB=$NOLUT
-      timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/$name" -- \
-        python3 "$ROOT/bench.py" $BENCH --data $data > "$OUT/$name.log" 2>&1 )
-    rc=$?; echo "$name rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+    # two passes of at most four counters each, as the guide prescribes (round 4 ran all seven in one pass: it fitted --
+    # gpurun_out/r4lds*/*.log show the pass accepted -- but a six-counter TCC pass of the same round hung until its limit,
+    # profiles/HISTORY.md, so nothing here relies on what happens to fit); the summary below reads both directories
+    for pass in a b; do
+      if [ $pass = a ]; then PMC="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"; else PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; fi
+      ( [ $lib = nolut ] && export RAWDEV_LIB=$NOLUT
+        timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/${name}_$pass" -- \
+          python3 "$ROOT/bench.py" $BENCH --data $data > "$OUT/${name}_$pass.log" 2>&1 )
+      rc=$?; echo "$name pass $pass rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+    done
   done
 done
 cd "$ROOT"
@@ -22,13 +28,14 @@ python3 - "$OUT" "$KERNEL" <<'PY'
 import csv, glob, sys, collections
 out=sys.argv[1]; KERNEL=sys.argv[2]
 for name in ("nolut_uniform","lut_uniform","nolut_gradient","lut_gradient"):
-    fs=glob.glob(f"{out}/{name}/*/*counter_collection.csv")
-    if not fs: print(name, "no counters"); continue
+    fs=glob.glob(f"{out}/{name}_a/*/*counter_collection.csv")+glob.glob(f"{out}/{name}_b/*/*counter_collection.csv")
+    if len(fs) < 2: print(name, "no counters"); continue
     acc=collections.defaultdict(float); n=0
-    for r in csv.DictReader(open(fs[0])):
-        if KERNEL not in r["Kernel_Name"]: continue
-        acc[r["Counter_Name"]]+=float(r["Counter_Value"])
-    ks=glob.glob(f"{out}/{name}/*/*kernel_trace.csv")
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            if KERNEL not in r["Kernel_Name"]: continue
+            acc[r["Counter_Name"]]+=float(r["Counter_Value"])
+    ks=glob.glob(f"{out}/{name}_a/*/*kernel_trace.csv")
     durs=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(ks[0])) if KERNEL in r["Kernel_Name"]]
     launches=len(durs); frames=launches*32
     if not launches: print(name, "no launches"); continue

@@ -18,7 +18,7 @@ step() {   # step <seconds> <logfile> <cmd...>
     if [ $rc -ge 124 ]; then echo "step killed/timed out: stopping"; exit $rc; fi
     return $rc
 }
-step 600 "$OUT/gate.log" python -m pytest tests/test_gpu_q8.py tests/test_gpu_parity.py tests/test_gpu_batch.py tests/test_gpu_export.py -x -q || exit 1
+step 600 "$OUT/gate.log" python -m pytest tests/test_gpu_q8.py tests/test_gpu_parity.py tests/test_gpu_batch.py tests/test_gpu_export.py -m gpu -x -q || exit 1
 step 120 "$OUT/valu_probe_new.txt" ./tools/valu_probe2 new
 cat "$OUT/valu_probe_new.txt"
 pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], d["roofline"]["us_per_frame"], "us/frame  verified", d["verified"])'

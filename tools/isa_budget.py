@@ -249,8 +249,11 @@ def main():
         blocks.append(cur)
     for blk in blocks:
         valu = [i for i in blk if i["op"].startswith("v_")]
-        ncold = sum(1 for i in valu if cold_stage.match(stage_of(i["loc"][0], i["loc"][1], stages)))
-        is_cold = bool(valu) and ncold * 2 > len(valu)
+        # (instructions without a source position -- line 0: selects and copies the compiler adds when it merges blocks --
+        # take the character of the attributable ones around them)
+        placed = [i for i in valu if i["loc"][1] != 0]
+        ncold = sum(1 for i in placed if cold_stage.match(stage_of(i["loc"][0], i["loc"][1], stages)))
+        is_cold = bool(placed) and ncold * 2 > len(placed)
         for i in blk:
             i["cold"] = is_cold
 
