@@ -72,6 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip 'extra_configs' (config 1, RGBA8, config-5 shape; N=1 only)")
     ap.add_argument("--no-hist", action="store_true")
     ap.add_argument("--no-box", action="store_true", help="skip the box's own copy / fill ceiling (roofline.box_*, ~0.1 s before the headline)")
+    ap.add_argument("--plane-stagger", type=int, default=-1,
+                    help="A/B (profiles/HISTORY.md, the launch-position question): carve the CFA planes out of ONE arena at a pitch of "
+                         "(plane rounded up to 2 MiB) + this many bytes (a multiple of 16; 0 = every plane starts 2 MiB-aligned); "
+                         "default -1 = one torch allocation per plane")
     ap.add_argument("--data", choices=["uniform", "gradient"], default="uniform",
                     help="uniform: i.i.d. 12-bit samples (SURVEY 8d, the headline); gradient: smooth ramp + 1 %% noise "
                          "(SURVEY 8d's second distribution: flat regions, same-bin histogram atomics, less bit toggling)")
@@ -428,14 +432,25 @@ def bound_measured_of(achieved_GBps, box_copy_GBps, valu):
                                    f"({ceiling:.0f} GB/s) vs valu issue {v:.3f}; `bound` is the declared roofline"}
 
 
-def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform"):
-    """Synthetic frames generated on the device, keyed by (seed, global frame index = first_index + f * stride)."""
+def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform", stagger=-1):
+    """Synthetic frames generated on the device, keyed by (seed, global frame index = first_index + f * stride).
+    stagger >= 0: the planes are views into one arena, plane f at f * (plane bytes rounded up to 2 MiB + stagger)."""
     cfas, params = [], []
+    arena, pitch, base = None, 0, 0
+    if stagger >= 0:
+        assert stagger % 16 == 0, "--plane-stagger must be a multiple of 16 bytes"
+        pitch = ((W * H * 2 + (2 << 20) - 1) // (2 << 20)) * (2 << 20) + stagger
+        arena = torch.empty(F * pitch + (2 << 20), dtype=torch.uint8, device=dev)
+        base = (-arena.data_ptr()) % (2 << 20)                       # the arena's first 2 MiB boundary
     for f in range(F):
         gidx = first_index + f * stride
         g = torch.Generator(device=dev)
         g.manual_seed(SEED + gidx)
-        if data == "uniform":
+        if data == "uniform" and arena is not None:
+            view = arena[base + f * pitch: base + f * pitch + W * H * 2].view(torch.int16).view(H, W)
+            view.copy_(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
+            cfas.append(view)
+        elif data == "uniform":
             cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
         else:                                             # a diagonal ramp whose slope and offset vary per frame, +-1 % noise
             yy = torch.arange(H, device=dev, dtype=torch.float32)[:, None] / H
@@ -884,7 +899,7 @@ def run_ranks(args):
 
     ident = device_identity(dev_index)
     box = measure_box(ra, dev_index) if not args.no_box else {}       # before the headline, outside its timed region (~0.1 s)
-    cfas, params = make_batch(torch, np, ra, dev, W, H, F, rank, world, args.data)     # frame i -> rank i mod N
+    cfas, params = make_batch(torch, np, ra, dev, W, H, F, rank, world, args.data, stagger=args.plane_stagger)     # frame i -> rank i mod N
     ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
@@ -974,6 +989,10 @@ def run_ranks(args):
         rule_backend = "nccl" if (backend == "nccl" or os.environ.get("RAWDEV_DIAG_ASSUME_NCCL") == "1") else backend
         diag, err2 = summarize_ranks(records, world, world_seen, rule_backend)
         result.update(diag)
+        # where the planes and surfaces of the first launch live (the launch-position question of profiles/HISTORY.md)
+        result["config"]["buffers"] = {"plane_stagger": args.plane_stagger,
+                                       "cfa_addr_mod_2MiB_first8": [c.data_ptr() % (2 << 20) for c in cfas[:8]],
+                                       "ring_addr_mod_2MiB": [r.data_ptr() % (2 << 20) for r in ring[:8]]}
         result["backend"] = backend if world > 1 else None
         try:
             result["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 else None

@@ -800,6 +800,15 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 #ifndef RD_NUM_SGPR
 #define RD_NUM_SGPR 80
 #endif
+// Round 5: the f32 instances also tell the compiler that 8 waves per SIMD is the target (amdgpu_waves_per_eu): __launch_bounds__(1024)
+// alone promises only 4, so its scheduler feels free to use up to 128 VGPRs and whether an instance stays under 64 is luck --
+// with the f32 surface's slider uniforms parked in VGPRs (RD_F32_PARK) four instances came out at 65-67.  With the attribute
+// the scheduler orders the code for <= 64 (the build still checks: no scratch, <= 64 VGPRs).  The narrow surfaces keep the
+// default (4, 8): they fit anyway and the attribute's instruction order costs them 4 issue cycles per tile (0.15-0.2 % measured,
+// profiles/r05_f32_park_ab.txt).
+#ifndef RD_WAVES_PER_EU
+#define RD_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(FMT == RD_FMT_RGBA_F32 ? 8 : 4, 8)))
+#endif
 #ifndef RD_SWEEP_POLICY
 #define RD_SWEEP_POLICY ""      // cache-policy bits of the sweeps' LDS-DMA loads (probe builds: " nt", " sc1", ...)
 #endif
@@ -888,9 +897,12 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         RD_PARK(wb_r); RD_PARK(wb_g); RD_PARK(wb_b); RD_PARK(kr); RD_PARK(kg); RD_PARK(kb);
         RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
         RD_PARK(den); RD_PARK(rden);                             // 36 uses per tile in the divide's FMA chains
-        if constexpr (FMT != RD_FMT_RGBA_F32) {                  // the narrower surfaces carry fewer live VGPRs: park six to eight more
+#ifndef RD_F32_PARK
+#define RD_F32_PARK 1          // A/B (tools/build_ab.sh): 0 = round 4's f32 kernel, its slider uniforms left in SGPRs
+#endif
+        if constexpr (FMT != RD_FMT_RGBA_F32 || RD_F32_PARK) {   // six to eight more: an SGPR source halves the issue rate of v_mul / v_add / v_fma
             RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
-            if constexpr (FMT != RD_FMT_RGB_U8) { RD_PARK(highlights); RD_PARK(shadows); }     // (RGB8's LDS repack needs the registers)
+            if constexpr (FMT != RD_FMT_RGB_U8 && FMT != RD_FMT_RGBA_F32) { RD_PARK(highlights); RD_PARK(shadows); }     // (RGB8's LDS repack and the f32 surface's pinned gamma need the registers)
         }
 #undef RD_PARK
     };
@@ -1501,7 +1513,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 // One frame, or one row band of a frame, per launch: rd_render*, the export ring, and rd_batch_develop when the
 // multi-frame launch is switched off (RD_BATCH_PERSISTENT=0).
 template <int FMT, bool HIST, int TILES, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
-__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
+__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR))) RD_WAVES_PER_EU
 rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
                  uint32_t unit0, uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k,
                  uint32_t tq_tmax, uint32_t *tq, rd_ku u_arg, uint32_t *slab32, unsigned long long *slab64)
@@ -1514,7 +1526,7 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
 // frame): the batch path.  Histogram counts of all frames meet in the workgroup's LDS table (u32: the host keeps
 // nframes * W * H below 2^32) and are added to its u64 slab row at the end of the launch.
 template <int FMT, bool HIST, int TILES, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
-__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR)))
+__global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR))) RD_WAVES_PER_EU
 rd_develop_batch(const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t W, uint32_t H, uint32_t tpu,
                  uint32_t tpu_magic, uint32_t tpf, uint32_t tpf_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
                  unsigned long long *slab64)

@@ -35,6 +35,9 @@ def main():
         dict(name="u16_full_range", h=12, w=16, params="random", wb=WB_DAYLIGHT, cm=CM_TEST, hi=65536),
         dict(name="black_level_64", h=12, w=16, params="random", wb=WB_DAYLIGHT, cm=CM_IDENTITY, bl=64),
         dict(name="random_64x96", h=64, w=96, params="random", wb=WB_DAYLIGHT, cm=CM_TEST),
+        # round 5 (appended: the random stream of the cases above is unchanged): a width that is not a multiple of the export
+        # kernel's 128-pixel tile -- 134 = one whole tile + a last tile pulled back over 61 of its quads -- and an odd height
+        dict(name="ragged_11x134", h=11, w=134, params="random", wb=WB_DAYLIGHT, cm=CM_TEST),
     ]
     out = {}
     for s in spec:
