@@ -73,9 +73,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-hist", action="store_true")
     ap.add_argument("--no-box", action="store_true", help="skip the box's own copy / fill ceiling (roofline.box_*, ~0.1 s before the headline)")
     ap.add_argument("--plane-stagger", type=int, default=-1,
-                    help="A/B (profiles/HISTORY.md, the launch-position question): carve the CFA planes out of ONE arena at a pitch of "
-                         "(plane rounded up to 2 MiB) + this many bytes (a multiple of 16; 0 = every plane starts 2 MiB-aligned); "
-                         "default -1 = one torch allocation per plane")
+                    help="A/B (profiles/r05_plane_stagger.txt, the launch-position question): -1 (default) = one torch allocation per CFA "
+                         "plane; >= 0 = the planes are views into ONE arena at a pitch of (plane rounded up to 2 MiB) + this many bytes "
+                         "(a multiple of 16; 0 = every plane starts 2 MiB-aligned)")
+    ap.add_argument("--ring-arena", type=int, default=0, help="A/B: 1 = the output ring is one allocation too; 0 (default) = one torch allocation per surface")
     ap.add_argument("--data", choices=["uniform", "gradient"], default="uniform",
                     help="uniform: i.i.d. 12-bit samples (SURVEY 8d, the headline); gradient: smooth ramp + 1 %% noise "
                          "(SURVEY 8d's second distribution: flat regions, same-bin histogram atomics, less bit toggling)")
@@ -432,6 +433,16 @@ def bound_measured_of(achieved_GBps, box_copy_GBps, valu):
                                    f"({ceiling:.0f} GB/s) vs valu issue {v:.3f}; `bound` is the declared roofline"}
 
 
+def alloc_ring(torch, dev, n, nbytes, arena=False):
+    """n surfaces of nbytes each: n torch allocations (default), or views into one allocation at a 2 MiB-rounded pitch."""
+    if not arena or n <= 1:
+        return [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(n)]
+    pitch = ((nbytes + (2 << 20) - 1) // (2 << 20)) * (2 << 20)
+    buf = torch.empty(n * pitch + (2 << 20), dtype=torch.uint8, device=dev)
+    base = (-buf.data_ptr()) % (2 << 20)
+    return [buf[base + i * pitch: base + i * pitch + nbytes] for i in range(n)]
+
+
 def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform", stagger=-1):
     """Synthetic frames generated on the device, keyed by (seed, global frame index = first_index + f * stride).
     stagger >= 0: the planes are views into one arena, plane f at f * (plane bytes rounded up to 2 MiB + stagger)."""
@@ -446,19 +457,21 @@ def make_batch(torch, np, ra, dev, W, H, F, first_index, stride, data="uniform",
         gidx = first_index + f * stride
         g = torch.Generator(device=dev)
         g.manual_seed(SEED + gidx)
-        if data == "uniform" and arena is not None:
+        def place(t):                                     # into the arena (same values), or as its own allocation
+            if arena is None:
+                return t
             view = arena[base + f * pitch: base + f * pitch + W * H * 2].view(torch.int16).view(H, W)
-            view.copy_(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
-            cfas.append(view)
-        elif data == "uniform":
-            cfas.append(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16))
+            view.copy_(t)
+            return view
+        if data == "uniform":
+            cfas.append(place(torch.randint(0, 4096, (H, W), generator=g, device=dev, dtype=torch.int16)))
         else:                                             # a diagonal ramp whose slope and offset vary per frame, +-1 % noise
             yy = torch.arange(H, device=dev, dtype=torch.float32)[:, None] / H
             xx = torch.arange(W, device=dev, dtype=torch.float32)[None, :] / W
             a = 0.25 + 0.5 * ((gidx * 37) % 16) / 16.0
             ramp = (a * xx + (1.0 - a) * yy) * 3600.0 + 200.0
             noise = (torch.rand((H, W), generator=g, device=dev) - 0.5) * 2.0 * 40.96
-            cfas.append((ramp + noise).clamp_(0, 4095).to(torch.int16))
+            cfas.append(place((ramp + noise).clamp_(0, 4095).to(torch.int16)))
             del yy, xx, ramp, noise
         params.append(ra.EditParams.random(np.random.default_rng([SEED, gidx])))
     return cfas, params
@@ -608,7 +621,7 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     fmt = {"f32": ra.FMT_RGBA_F32, "f16": ra.FMT_RGBA_F16, "u8": ra.FMT_RGBA_U8, "rgb8": ra.FMT_RGB_U8}[fmt_name]
     bpp = ra.BYTES_PER_PIXEL[fmt]
     F = len(cfas)
-    ring = [torch.empty(H * W * bpp, dtype=torch.uint8, device=dev) for _ in range(ring_n)]
+    ring = alloc_ring(torch, dev, ring_n, H * W * bpp)
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
     saved = os.environ.get("RD_BATCH_PERSISTENT")
     if tiled:
@@ -900,7 +913,7 @@ def run_ranks(args):
     ident = device_identity(dev_index)
     box = measure_box(ra, dev_index) if not args.no_box else {}       # before the headline, outside its timed region (~0.1 s)
     cfas, params = make_batch(torch, np, ra, dev, W, H, F, rank, world, args.data, stagger=args.plane_stagger)     # frame i -> rank i mod N
-    ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
+    ring = alloc_ring(torch, dev, max(1, args.ring), H * W * bpp_out, arena=bool(args.ring_arena))
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
@@ -990,7 +1003,7 @@ def run_ranks(args):
         diag, err2 = summarize_ranks(records, world, world_seen, rule_backend)
         result.update(diag)
         # where the planes and surfaces of the first launch live (the launch-position question of profiles/HISTORY.md)
-        result["config"]["buffers"] = {"plane_stagger": args.plane_stagger,
+        result["config"]["buffers"] = {"plane_stagger": args.plane_stagger, "ring_arena": args.ring_arena,
                                        "cfa_addr_mod_2MiB_first8": [c.data_ptr() % (2 << 20) for c in cfas[:8]],
                                        "ring_addr_mod_2MiB": [r.data_ptr() % (2 << 20) for r in ring[:8]]}
         result["backend"] = backend if world > 1 else None
@@ -1091,8 +1104,8 @@ def run_node(args):
     per_dev = []
     for r, d in enumerate(devices):
         dev = torch.device("cuda", d)
-        cfas, params = make_batch(torch, np, ra, dev, W, H, F, r, N, args.data)
-        ring = [torch.empty(H * W * bpp_out, dtype=torch.uint8, device=dev) for _ in range(max(1, args.ring))]
+        cfas, params = make_batch(torch, np, ra, dev, W, H, F, r, N, args.data, stagger=args.plane_stagger)
+        ring = alloc_ring(torch, dev, max(1, args.ring), H * W * bpp_out, arena=bool(args.ring_arena))
         per_dev.append((cfas, params, ring))
     for d in set(devices):
         torch.cuda.synchronize(d)
