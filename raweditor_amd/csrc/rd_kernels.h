@@ -919,16 +919,46 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         if constexpr (FMT == RD_FMT_RGBA_F16) asm volatile("" : "+v"(kc.f16_ka), "+v"(kc.f16_kb));
     }
     typedef uint32_t rd_u4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t lh[HIST ? 768 * RD_HK : 4];
     __shared__ __attribute__((aligned(16))) uint32_t qlut[Q8LUT ? RD_Q8_LUT_LDS_WORDS : 4];
     __shared__ __attribute__((aligned(16))) uint16_t hfine[F16LUT ? RD_F16_LUT_FINE_LDS : 8];
     __shared__ __attribute__((aligned(16))) uint32_t hcoarse[F16LUT ? RD_F16_LUT_COARSE_LDS : 4];
     __shared__ rd_f4 stage[FMT == RD_FMT_RGBA_F32 ? RD_BLOCK * 3 : 1];
     __shared__ uint16_t rgb16[FMT == RD_FMT_RGB_U8 ? RD_WAVES * 384 : 1];   // per wave: 2 rows x 384 B
     __shared__ rd_f4 pf_dump[BURST ? 64 : 1];                    // where the LDS-DMA sweeps land (never read)
-    if constexpr (Q8LUT) rd_q8_lut_load(qlut);
-    if constexpr (F16LUT) rd_f16_lut_load(hfine, hcoarse);
-    if (HIST) rd_hist_zero(lh);
+    // Workgroup prologue (round 5: one phase instead of three).  Every global load of the code / half tables is issued first
+    // -- up to five 16-byte loads per lane in flight -- the histogram is zeroed (16 bytes per store) while they travel, then
+    // the tables are written to LDS and ONE barrier ends it.  It was: table loop (a dependent load -> LDS store per trip,
+    // three trips for the f16 tables), barrier, second table, barrier, 4-byte zeroing loop, barrier -- several microseconds at
+    // the head of EVERY launch, which a launch per row band (BASELINE config 5 as worded: 128 launches per step) pays 8
+    // times per frame.
+    {
+        typedef uint32_t rd_u4v __attribute__((ext_vector_type(4)));
+        constexpr uint32_t NQ = Q8LUT ? RD_Q8_LUT_LDS_WORDS / 4u : 0u, NF = F16LUT ? RD_F16_LUT_FINE_LDS / 8u : 0u,
+                           NC = F16LUT ? RD_F16_LUT_COARSE_LDS / 4u : 0u;
+        constexpr uint32_t KQ = (NQ + RD_BLOCK - 1u) / RD_BLOCK, KF = (NF + RD_BLOCK - 1u) / RD_BLOCK, KC = (NC + RD_BLOCK - 1u) / RD_BLOCK;
+        const rd_u4v *qs = reinterpret_cast<const rd_u4v *>(rd_q8_lut_dev), *fs = reinterpret_cast<const rd_u4v *>(rd_f16_fine_dev),
+                     *cs = reinterpret_cast<const rd_u4v *>(rd_f16_coarse_dev);
+        rd_u4v vq[KQ ? KQ : 1], vf[KF ? KF : 1], vc[KC ? KC : 1];
+#pragma unroll
+        for (uint32_t k = 0; k < KQ; ++k) { const uint32_t i = threadIdx.x + k * RD_BLOCK; if (i < NQ) vq[k] = qs[i]; }
+#pragma unroll
+        for (uint32_t k = 0; k < KF; ++k) { const uint32_t i = threadIdx.x + k * RD_BLOCK; if (i < NF) vf[k] = fs[i]; }
+#pragma unroll
+        for (uint32_t k = 0; k < KC; ++k) { const uint32_t i = threadIdx.x + k * RD_BLOCK; if (i < NC) vc[k] = cs[i]; }
+        if (HIST) {
+            static_assert((768u * RD_HK) % 4u == 0, "histogram table in 16-byte pieces");
+            const rd_u4v z = { 0u, 0u, 0u, 0u };
+            for (uint32_t i = threadIdx.x; i < 768u * RD_HK / 4u; i += RD_BLOCK) reinterpret_cast<rd_u4v *>(lh)[i] = z;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < KQ; ++k) { const uint32_t i = threadIdx.x + k * RD_BLOCK; if (i < NQ) reinterpret_cast<rd_u4v *>(qlut)[i] = vq[k]; }
+#pragma unroll
+        for (uint32_t k = 0; k < KF; ++k) { const uint32_t i = threadIdx.x + k * RD_BLOCK; if (i < NF) reinterpret_cast<rd_u4v *>(hfine)[i] = vf[k]; }
+#pragma unroll
+        for (uint32_t k = 0; k < KC; ++k) { const uint32_t i = threadIdx.x + k * RD_BLOCK; if (i < NC) reinterpret_cast<rd_u4v *>(hcoarse)[i] = vc[k]; }
+        if (Q8LUT || F16LUT || HIST) __syncthreads();
+    }
     if constexpr (FMT == RD_FMT_RGBA_F32) {
         // The store stage holds [lane][c1, c2, c3] as RGBA; alpha is 1.0 for every pixel of every tile, so it is written
         // here once and the tiles only ever write r, g, b (12 bytes) next to it: no per-tile assembly of {r, g, b, 1}

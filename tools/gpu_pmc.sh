@@ -19,6 +19,7 @@ C5="--width 11648 --height 8736 --format f16 --row-bands 8 --frames 8 --ring 4 -
 pass() {   # name, env assignments ("-" for none), counters (comma separated), bench arguments...
   local name=$1 envs=$2 ctrs=$3; shift 3
   if [ "$ONLY" = f16 ]; then case $name in f16_*|c5_*) ;; *) return 0;; esac; fi
+  if [ "$ONLY" = ragged ]; then case $name in *_ragged_*|f32_perframe_noburst_*) ;; *) return 0;; esac; fi
   echo "== $name [$envs] $ctrs"
   ( [ "$envs" != "-" ] && export $envs
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d "$OUT/$name" -- \
@@ -32,6 +33,11 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   pass f16_multi_$CTR      -                                    $CTR $BENCH --format f16
   pass u8_multi_$CTR       -                                    $CTR $BENCH --format u8
   pass c5_multi_$CTR       -                                    $CTR $C5
+  # round 5: a width that is not a multiple of the 128-px tile (the overlapped-last-tile instances): no re-read, and the
+  # duplicate stores of the overlap are 16 of 6000 px per row
+  pass f32_ragged_multi_$CTR -                                  $CTR $BENCH --width 6000 --height 4000
+  pass f16_ragged_multi_$CTR -                                  $CTR $BENCH --width 6000 --height 4000 --format f16
+  pass u8_ragged_multi_$CTR  -                                  $CTR $BENCH --width 6000 --height 4000 --format u8
 done
 SQ1=SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_INSTS_VALU,SQ_ACTIVE_INST_VALU,SQ_INST_CYCLES_VMEM_WR,SQ_WAIT_INST_ANY,SQ_WAIT_ANY,SQ_ACTIVE_INST_ANY,GRBM_GUI_ACTIVE
 SQ2=SQ_INSTS_VALU_TRANS_F32,SQ_INSTS_VMEM_WR,SQ_INSTS_VMEM_RD,SQ_INSTS_LDS,SQ_INSTS_SALU,SQ_INSTS_SMEM,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_VMEM,GRBM_GUI_ACTIVE

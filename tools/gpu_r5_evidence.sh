@@ -30,6 +30,10 @@ if [ "$PART" = a ]; then
     ( cd /tmp && step 600 "$OLDPWD/$OUT/rocprof_run.log" rocprofv3 --kernel-trace --stats --output-format csv \
         -d "$OLDPWD/$OUT/rocprof" -- python3 "$OLDPWD/bench.py" --no-cpu-baseline )
     for f in $(find "$OUT/rocprof" -name "*kernel_stats*.csv" | head -1); do head -14 "$f" | cut -c1-200; done
+    # the same without the extras: the headline kernel's launches only (the extras run the same instance on other batches)
+    ( cd /tmp && step 600 "$OLDPWD/$OUT/rocprof_headline_run.log" rocprofv3 --kernel-trace --stats --output-format csv \
+        -d "$OLDPWD/$OUT/rocprof_headline" -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --no-extra )
+    for f in $(find "$OUT/rocprof_headline" -name "*kernel_stats*.csv" | head -1); do head -4 "$f" | cut -c1-200; done
 elif [ "$PART" = b ]; then
     step 1000 "$OUT/fuzz.log" python -m tests.fuzz_parity ${3:-100000} ${4:-51}
     step 600 "$OUT/soak.log" python tools/soak.py 10000

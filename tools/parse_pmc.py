@@ -73,7 +73,8 @@ def main(out_dir, tag):
           f"16-B LDS-DMA reads x2.0 (guide)")
     rows = [("f32_perframe_noburst", "f32", "per_frame_noburst", False), ("f32_perframe", "f32", "per_frame", True),
             ("f32_multi", "f32", "multi", True), ("f16_multi", "f16", "multi", False), ("u8_multi", "u8", "multi", False),
-            ("c5_multi", "f16", "multi", False)]
+            ("c5_multi", "f16", "multi", False),
+            ("f32_ragged_multi", "f32", "multi", True), ("f16_ragged_multi", "f16", "multi", False), ("u8_ragged_multi", "u8", "multi", False)]
     bpp = {"f32": 16, "f16": 8, "u8": 4}
     for name, fmt, mode, burst in rows:
         f, r = per_frame(name, "FETCH_SIZE")
