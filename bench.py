@@ -623,16 +623,18 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     F = len(cfas)
     ring = alloc_ring(torch, dev, ring_n, H * W * bpp)
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
-    saved = os.environ.get("RD_BATCH_PERSISTENT")
+    saved = {k: os.environ.get(k) for k in ("RD_BATCH_PERSISTENT", "RD_BATCH_STREAMS")}
     if tiled:
         os.environ["RD_BATCH_PERSISTENT"] = "0"              # read by rd_batch_create
+        os.environ.setdefault("RD_BATCH_STREAMS", "2")       # the band launches alternate between two streams: the tail of one under the head of the next (+3 %)
     try:
         be = ra.BatchExporter(dev_index, W, H, fmt, True)
     finally:
         if tiled:
-            os.environ.pop("RD_BATCH_PERSISTENT", None)
-            if saved is not None:
-                os.environ["RD_BATCH_PERSISTENT"] = saved
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
     variants = [params, swapped_halves(params)]
     arrays = [be.make_frames([c.data_ptr() for c in cfas], [ring[i % ring_n].data_ptr() for i in range(F)], v, WB, CM)
               for v in variants]
@@ -863,7 +865,7 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
                                            "need no row bands of their own", "multi", valu_ns=valu_ns)
     out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3, stream,
                                                  "the same 16 x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
-                                                 "8 row-band launches per frame (RD_BATCH_PERSISTENT=0)", "per_frame", tiled=True)
+                                                 "8 row-band launches per frame (RD_BATCH_PERSISTENT=0), alternating between two streams (RD_BATCH_STREAMS=2)", "per_frame", tiled=True)
     del c5
     out["ragged_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
     out["seconds"] = round(time.perf_counter() - t0, 1)

@@ -102,6 +102,15 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     # the narrow surfaces carry the VALU roofline of their threshold-table kernels (round 4: no transcendental left in either)
     assert ex["batch_rgba8"]["roofline"]["bound"] == "valu" and ex["batch_rgba8"]["roofline"]["valu_issue_cycles_per_tile"] == 698
     assert ex["config5_shape_f16"]["roofline"]["bound"] == "valu" and ex["config5_shape_f16"]["roofline"]["valu_issue_cycles_per_tile"] == 876
+    # round 5: a frame width that is not a multiple of the 128-px tile beside the headline's, all four surfaces, oracle-checked
+    rw = ex["ragged_width"]
+    assert rw["verified"] is True and "6000x4000" in rw["config"]
+    for k in ("f32", "f16", "u8", "rgb8"):
+        assert rw[k]["verified"] is True and 0.8 < rw[k]["ns_per_px_ratio"] < 1.25, (k, rw[k])
+    # the f32 kernel's issue budget after the uniforms were parked (round 5), and the bound as this run's fractions say it
+    assert r["roofline"]["valu_issue_cycles_per_tile"] == 1290 and r["roofline"]["bound"] == "hbm"
+    assert r["roofline"]["bound_measured"] in ("hbm", "valu", "hbm+valu") and "bound_measured_note" in r["roofline"]
+    assert r["config"]["buffers"]["plane_stagger"] == -1 and len(r["config"]["buffers"]["cfa_addr_mod_2MiB_first8"]) == 8
     # the box's own ceilings, measured in this run (item 4)
     rf = r["roofline"]
     assert rf["box_copy_GBps"] > 3000 and rf["box_fill_GBps"] > 3000 and 0 < rf["frac_of_box_copy"] < 1.2
