@@ -37,6 +37,7 @@ if [ "$PART" = a ]; then
 elif [ "$PART" = b ]; then
     step 1000 "$OUT/fuzz.log" python -m tests.fuzz_parity ${3:-100000} ${4:-51}
     step 600 "$OUT/soak.log" python tools/soak.py 10000
+    step 600 "$OUT/soak_ragged.log" python tools/soak.py 5000 6000 4000
 else
     bash tools/gpu_pmc.sh "$TAG"
 fi

@@ -11,7 +11,9 @@ import numpy as np
 import raweditor_amd as ra
 from tests.gpu_util import DevBuf, sync
 
-W, H = 6016, 4016
+# python tools/soak.py [reps=2000] [width=6016] [height=4016]   (round 5: e.g. 6000 4000 -- every row pair ends in an overlapped tile)
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 6016
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 4016
 WB = (2.0, 1.0, 1.5, 1.0)
 CM = (1.6, -0.4, -0.2, -0.3, 1.5, -0.2, 0.0, -0.5, 1.5)
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
@@ -21,7 +23,7 @@ NF = 8
 def main():
     rng = np.random.default_rng(0x52415745)
     ins = [DevBuf.from_array(rng.integers(0, 4096, (H, W), dtype=np.uint16)) for _ in range(NF)]
-    for fmt, name, bands in ((ra.FMT_RGBA_F32, "f32", 1), (ra.FMT_RGBA_U8, "u8", 3)):
+    for fmt, name, bands in ((ra.FMT_RGBA_F32, "f32", 1), (ra.FMT_RGBA_U8, "u8", 3)) + (((ra.FMT_RGB_U8, "rgb8", 1),) if W % 128 else ()):
         bpp = ra.BYTES_PER_PIXEL[fmt]
         outs = [DevBuf(H * W * bpp) for _ in range(NF)]
         hist = DevBuf(768 * 8)
