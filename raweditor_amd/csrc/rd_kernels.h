@@ -900,7 +900,9 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 #ifndef RD_F32_PARK
 #define RD_F32_PARK 1          // A/B (tools/build_ab.sh): 0 = round 4's f32 kernel, its slider uniforms left in SGPRs
 #endif
-        if constexpr (FMT != RD_FMT_RGBA_F32 || RD_F32_PARK) {   // six to eight more: an SGPR source halves the issue rate of v_mul / v_add / v_fma
+        // six to eight more: an SGPR source halves the issue rate of v_mul / v_add / v_fma.  (f32: in the multi-frame kernel only --
+        // the headline's; the single-frame instances sit at 63-64 VGPRs without them and one of them spilled with them)
+        if constexpr (FMT != RD_FMT_RGBA_F32 || (RD_F32_PARK && MULTI)) {
             RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
             if constexpr (FMT != RD_FMT_RGB_U8 && FMT != RD_FMT_RGBA_F32) { RD_PARK(highlights); RD_PARK(shadows); }     // (RGB8's LDS repack and the f32 surface's pinned gamma need the registers)
         }
@@ -1295,12 +1297,13 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 const rd_f4 va = st[has_a ? ja : jb];                  // a missing row re-stores the other one: the select is
                 const rd_f4 vb = st[has_b ? jb : ja];                  // made on the LDS index (2 per half), not on 8 floats
                 if (FULL || px < W) {
+                    // wave-uniform base (row + the tile's first column: SALU) + the lane's own pixel, like the loads
 #ifdef RD_ST_PLAIN
-                    o[row_a_px + px] = va;
-                    o[row_b_px + px] = vb;
+                    (o + (row_a_px + (size_t)q0 * 2u))[p] = va;
+                    (o + (row_b_px + (size_t)q0 * 2u))[p] = vb;
 #else
-                    __builtin_nontemporal_store(va, o + row_a_px + px);
-                    __builtin_nontemporal_store(vb, o + row_b_px + px);
+                    __builtin_nontemporal_store(va, (o + (row_a_px + (size_t)q0 * 2u)) + p);
+                    __builtin_nontemporal_store(vb, (o + (row_b_px + (size_t)q0 * 2u)) + p);
 #endif
                 }
             }
