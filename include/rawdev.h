@@ -214,7 +214,9 @@ typedef struct rd_frame {
 } rd_frame;
 
 /* A batch context owns the histogram slab for frames of one size/format on one device.  Use one context per
- * stream and per thread (the accumulator is private to the context; calls on one context are not re-entrant). */
+ * stream and per thread (the accumulator is private to the context; calls on one context are not re-entrant).
+ * Frame sizes: any height; the width must be even (RD_ERR_UNSUPPORTED otherwise: rd_render serves odd widths), and
+ * for RD_FMT_RGB_U8 at least 128.  Every even width from 128 up runs at the full rate, a multiple of 128 or not. */
 int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format,
                     uint32_t with_histogram, rd_batch **out);
 void rd_batch_destroy(rd_batch *b);
@@ -289,7 +291,7 @@ int rd_node_batch_reduce_kind(const rd_node_batch *nb);
  * blocking map/copy (pipeline.rs:552-605, "1-2 s for 24 MP") becomes a ring of pinned host buffers filled by
  * asynchronous D2H copies on a second stream, so the copy of frame i overlaps the kernel of frame i+1.
  * `format` is normally RD_FMT_RGBA_U8 (PNG path, main.rs:1767-1775) or RD_FMT_RGB_U8 (JPEG path: the alpha strip
- * of main.rs:1777-1786 is fused into the kernel and a quarter of the PCIe bytes disappears). */
+ * of main.rs:1777-1786 is fused into the kernel and a quarter of the PCIe bytes disappears).  Widths: as rd_batch_create. */
 typedef struct rd_exporter rd_exporter;
 int rd_exporter_create(int device, uint32_t width, uint32_t height, uint32_t format, uint32_t math_mode,
                        uint32_t n_slots, rd_exporter **out);

@@ -16,7 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librawdev.so")
 SOURCES = ["rawdev.hip"]
-HEADERS = ["rd_math.h", "rd_uniforms.h", "rd_kernels.h", "rd_ljpeg.h", "rd_copy_pool.h", "rd_host_pipeline.inl", "rd_host_batch.inl", "rd_host_diag.inl", os.path.join("..", "..", "include", "rawdev.h")]
+HEADERS = ["rd_math.h", "rd_uniforms.h", "rd_kernels.h", "rd_ljpeg.h", "rd_copy_pool.h", "rd_node_worker.h", "rd_host_pipeline.inl", "rd_host_batch.inl", "rd_host_diag.inl", os.path.join("..", "..", "include", "rawdev.h")]
 # -fno-slp-vectorize: what the SLP vectoriser packs into v_pk_*_f32 costs more in SGPR pairs, register moves and spills
 # than the packed issue rate returns (measured 94-98 us against 82-89 us per frame), and a packed
 # operand pair that happens to contain a pending load's register makes hipcc drain the store queue mid-loop (false

@@ -30,6 +30,7 @@ struct rd_copy_pool {
     {
         static rd_copy_pool *pool = [] {
             rd_copy_pool *p = new rd_copy_pool;
+            p->jobs.reserve(32);                  // helpers + 1 pieces per copy: push_back below never allocates
             const char *e = getenv("RD_COPY_THREADS");
             long want = e && *e ? strtol(e, nullptr, 10) : 4;
             const long hw = (long)std::thread::hardware_concurrency();

@@ -397,63 +397,7 @@ rd_rccl_api &rd_rccl()
 
 enum { RD_NODE_REDUCE_NONE = 0, RD_NODE_REDUCE_RCCL = 1, RD_NODE_REDUCE_HOST = 2 };
 
-// One host thread per device, for the life of the node batch (round 5; rounds 2-4 started and joined N threads inside every
-// rd_node_batch_develop call -- 20 ms apart in the bench -- and a thread that failed to start there took the process down:
-// the already started ones were destroyed joinable).  A worker sleeps on its condition variable, runs the job it is handed
-// -- a plain function pointer + context: posting allocates nothing and cannot throw -- inside its own catch-all, and
-// reports status + message.  Its device is current for its whole life, so the per-call device guard finds nothing to do.
-struct rd_node_worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    int (*call)(void *ctx, uint32_t d) = nullptr;
-    void *ctx = nullptr;
-    uint32_t index = 0;
-    int device = 0;
-    bool has_job = false, done = false, quit = false;
-    int rc = RD_OK;
-    char msg[sizeof g_err] = "";
-
-    void loop()
-    {
-        (void)hipSetDevice(device);
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [this] { return has_job || quit; });
-            if (quit) return;
-            has_job = false;
-            int (*fn)(void *, uint32_t) = call;
-            void *c = ctx;
-            lk.unlock();
-            int r;
-            try { r = fn(c, index); }
-            catch (...) { r = rd_caught("rd_node_batch worker"); }           // nothing leaves a thread either: that would be std::terminate
-            lk.lock();
-            rc = r;
-            snprintf(msg, sizeof msg, "%s", r ? rd_last_error() : "");
-            done = true;
-            cv.notify_all();
-        }
-    }
-    void post(int (*fn)(void *, uint32_t), void *c)
-    {
-        { std::lock_guard<std::mutex> lk(mu); call = fn; ctx = c; done = false; has_job = true; }
-        cv.notify_all();
-    }
-    int wait()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this] { return done; });
-        return rc;
-    }
-    void stop()
-    {
-        if (!th.joinable()) return;
-        { std::lock_guard<std::mutex> lk(mu); quit = true; }
-        cv.notify_all();
-        th.join();
-    }
-};
+#include "rd_node_worker.h"                   // one host thread per device (plain C++: tests/cpp/test_node_worker.cpp runs it under TSan)
 
 struct rd_node_batch {
     uint32_t n = 0, w = 0, h = 0, fmt = 0;
@@ -564,6 +508,9 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
         for (uint32_t d = 0; d < n_devices; ++d) {
             rd_node_worker &w = nb->workers[d];
             w.index = d; w.device = devices[d];
+            w.on_start = [](int dev) { (void)hipSetDevice(dev); };
+            w.caught = rd_caught;
+            w.last_error = rd_last_error;
             try {
                 RD_FAULT_POINT("node.thread");
                 w.th = std::thread([&w] { w.loop(); });
