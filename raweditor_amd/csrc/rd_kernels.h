@@ -801,11 +801,11 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 #define RD_NUM_SGPR 80
 #endif
 // Round 5: the f32 instances also tell the compiler that 8 waves per SIMD is the target (amdgpu_waves_per_eu): __launch_bounds__(1024)
-// alone promises only 4, so its scheduler feels free to use up to 128 VGPRs and whether an instance stays under 64 is luck --
-// with the f32 surface's slider uniforms parked in VGPRs (RD_F32_PARK) four instances came out at 65-67.  With the attribute
-// the scheduler orders the code for <= 64 (the build still checks: no scratch, <= 64 VGPRs).  The narrow surfaces keep the
-// default (4, 8): they fit anyway and the attribute's instruction order costs them 4 issue cycles per tile (0.15-0.2 % measured,
-// profiles/r05_f32_park_ab.txt).
+// alone promises only 4, so its scheduler feels free to use up to 128 VGPRs and whether an instance stays under 64 is luck
+// (with the slider uniforms parked, RD_F32_PARK, four instances came out at 65-67).  With the attribute the scheduler orders the
+// code for <= 64 (the build still checks: no scratch, <= 64 VGPRs); measured neutral on the f32 kernel (75.36 vs 75.33 us per
+// frame, alternating).  The narrow surfaces keep the default (4, 8): they fit anyway and the attribute's instruction order
+// costs them 4 issue cycles per tile (0.15-0.2 % measured, profiles/r05_f32_park_ab.txt).
 #ifndef RD_WAVES_PER_EU
 #define RD_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(FMT == RD_FMT_RGBA_F32 ? 8 : 4, 8)))
 #endif
@@ -898,10 +898,11 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         RD_PARK(m[0]); RD_PARK(m[1]); RD_PARK(m[2]); RD_PARK(m[3]); RD_PARK(m[4]); RD_PARK(m[5]); RD_PARK(m[6]); RD_PARK(m[7]); RD_PARK(m[8]);
         RD_PARK(den); RD_PARK(rden);                             // 36 uses per tile in the divide's FMA chains
 #ifndef RD_F32_PARK
-#define RD_F32_PARK 1          // A/B (tools/build_ab.sh): 0 = round 4's f32 kernel, its slider uniforms left in SGPRs
-#endif
-        // six to eight more: an SGPR source halves the issue rate of v_mul / v_add / v_fma.  (f32: in the multi-frame kernel only --
-        // the headline's; the single-frame instances sit at 63-64 VGPRs without them and one of them spilled with them)
+#define RD_F32_PARK 0          // 1 = the f32 multi-frame kernel parks its slider uniforms too (tools/build_ab_libs.sh: librawdev_r5park.so).
+#endif                         // Measured (profiles/r05_f32_park_ab.txt): 84 fewer issue cycles per tile, 0.0 % on boxes at their memory
+                               // floor and -0.25 % on fast boxes, where it also never reached the faster of the two placement levels: off.
+        // six to eight more: an SGPR source halves the issue rate of v_mul / v_add / v_fma.  (f32: only with RD_F32_PARK, and then in
+        // the multi-frame kernel only; the single-frame instances sit at 63-64 VGPRs without them and one of them spilled with them)
         if constexpr (FMT != RD_FMT_RGBA_F32 || (RD_F32_PARK && MULTI)) {
             RD_PARK(em); RD_PARK(cf); RD_PARK(blacks); RD_PARK(s); RD_PARK(oms); RD_PARK(vibrance);
             if constexpr (FMT != RD_FMT_RGB_U8 && FMT != RD_FMT_RGBA_F32) { RD_PARK(highlights); RD_PARK(shadows); }     // (RGB8's LDS repack and the f32 surface's pinned gamma need the registers)

@@ -107,8 +107,9 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert rw["verified"] is True and "6000x4000" in rw["config"]
     for k in ("f32", "f16", "u8", "rgb8"):
         assert rw[k]["verified"] is True and 0.8 < rw[k]["ns_per_px_ratio"] < 1.25, (k, rw[k])
-    # the f32 kernel's issue budget after the uniforms were parked (round 5), and the bound as this run's fractions say it
-    assert r["roofline"]["valu_issue_cycles_per_tile"] == 1276 and r["roofline"]["bound"] == "hbm"
+    # the f32 kernel's issue budget (round 5: scalar-base store addresses; parking the slider uniforms measured negative and is off),
+    # and the bound as this run's fractions say it
+    assert r["roofline"]["valu_issue_cycles_per_tile"] == 1360 and r["roofline"]["bound"] == "hbm"
     assert r["roofline"]["bound_measured"] in ("hbm", "valu", "hbm+valu") and "bound_measured_note" in r["roofline"]
     assert r["config"]["buffers"]["plane_stagger"] == -1 and len(r["config"]["buffers"]["cfa_addr_mod_2MiB_first8"]) == 8
     # the box's own ceilings, measured in this run (item 4)

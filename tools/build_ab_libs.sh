@@ -5,7 +5,8 @@
 #   tools/librawdev_r4nof16lut.so  -DRD_F16_LUT=0   RGBA-f16 halves + codes by the shortcut instead of the two-level tables
 #   tools/librawdev_r5base.so      -DRD_F32_PARK=0 -DRD_WAVES_PER_EU=   round 4's register arrangement: the f32 kernel's slider
 #                                                   uniforms stay in SGPRs, no waves-per-SIMD target for the compiler
-#   tools/librawdev_r5nopark.so    -DRD_F32_PARK=0  the waves-per-SIMD attribute alone
+#   tools/librawdev_r5nopark.so    -DRD_F32_PARK=0  the waves-per-SIMD attribute alone (= the product since the A/B)
+#   tools/librawdev_r5park.so      -DRD_F32_PARK=1  six slider uniforms of the f32 multi-frame kernel parked in VGPRs (dropped)
 # `bash tools/build_ab_libs.sh r5` builds only the round-5 pair.
 set -eu
 cd "$(dirname "$0")/.."
@@ -16,5 +17,6 @@ if [ "${1:-all}" != r5 ]; then
 fi
 /opt/rocm/bin/hipcc $FLAGS -DRD_F32_PARK=0 "-DRD_WAVES_PER_EU=" -o tools/librawdev_r5base.so raweditor_amd/csrc/rawdev.hip &
 /opt/rocm/bin/hipcc $FLAGS -DRD_F32_PARK=0 -o tools/librawdev_r5nopark.so raweditor_amd/csrc/rawdev.hip &
+/opt/rocm/bin/hipcc $FLAGS -DRD_F32_PARK=1 -o tools/librawdev_r5park.so raweditor_amd/csrc/rawdev.hip &
 wait
 ls -la tools/librawdev_r*.so

@@ -18,7 +18,7 @@ d=json.load(open('$OUT/$name.json')); r=d['roofline']
 print('%-22s %9.1f MP/s  %7.2f us/frame  frac %.4f  valu %s' % ('$name', d['value'], r['us_per_frame'], r['frac'], r.get('valu_issue_frac')))"
 }
 for i in $(seq 1 $N); do
-  run f32_product_$i "" 
+  run f32_parked_$i $ROOT/tools/librawdev_r5park.so
   run f32_r4base_$i $ROOT/tools/librawdev_r5base.so
   run f32_nopark_$i $ROOT/tools/librawdev_r5nopark.so
 done
