@@ -1102,6 +1102,10 @@ def run_node(args):
     with_hist = not args.no_hist
     math_mode = ra.MATH_CONTRACTED if args.math == "contracted" else ra.MATH_STRICT
 
+    # (the box probe first, as in the ranks host: what is allocated and freed before the batch's buffers decides where the
+    #  driver places them, and a launch's time follows that placement by +-1.5 % -- profiles/r05_plane_stagger.txt; the two
+    #  hosts are compared on the same order of allocations)
+    box = measure_box(ra, devices[0]) if not args.no_box else {}
     # frame i of the call belongs to devices[i mod N]: F frames per device, interleaved
     per_dev = []
     for r, d in enumerate(devices):
@@ -1113,7 +1117,6 @@ def run_node(args):
         torch.cuda.synchronize(d)
     nb = ra.NodeBatch(devices, W, H, fmt, with_hist, math_mode=math_mode)
     idents = [device_identity(d) for d in devices]
-    box = measure_box(ra, devices[0]) if not args.no_box else {}
 
     def frame_array(swap):
         cp, op, pp = [], [], []
