@@ -354,6 +354,7 @@ struct rd_scratch {
         uint32_t *tq = nullptr;
         uint32_t *slab32 = nullptr;
         hipEvent_t done = nullptr;
+        bool recorded = false;                   // `done` marks the entry's LAST use (see used())
         bool dirty = false;
         uint64_t stamp = 0;
     };
@@ -387,14 +388,21 @@ struct rd_scratch {
             idx = (int)ents.size() - 1;
         }
         if (idx < 0) {                                           // recycle: least recently used among the finished ones
+            // (an entry whose last use carries no marker -- it was used while the table still had room, see used() -- may be
+            //  in flight for all we know: one device synchronise settles them all; the 17th stream of a pipeline is rare)
+            bool unknown = false;
+            for (const entry &e : ents) unknown = unknown || !e.recorded;
+            const bool drained = unknown && hipDeviceSynchronize() == hipSuccess;
+            if (unknown && !drained) for (entry &e : ents) e.dirty = true;
             int lru_done = -1, lru_any = 0;
             for (size_t i = 0; i < ents.size(); ++i) {
                 if (ents[i].stamp < ents[(size_t)lru_any].stamp) lru_any = (int)i;
-                if (hipEventQuery(ents[i].done) == hipSuccess && (lru_done < 0 || ents[i].stamp < ents[(size_t)lru_done].stamp))
+                const bool done = ents[i].recorded ? hipEventQuery(ents[i].done) == hipSuccess : drained;
+                if (done && (lru_done < 0 || ents[i].stamp < ents[(size_t)lru_done].stamp))
                     lru_done = (int)i;
             }
             idx = lru_done >= 0 ? lru_done : lru_any;
-            if (lru_done < 0 && hipEventSynchronize(ents[(size_t)idx].done) != hipSuccess) ents[(size_t)idx].dirty = true;
+            if (lru_done < 0 && (!ents[(size_t)idx].recorded || hipEventSynchronize(ents[(size_t)idx].done) != hipSuccess)) ents[(size_t)idx].dirty = true;
             ents[(size_t)idx].stream = s;
         }
         entry &e = ents[(size_t)idx];
@@ -410,8 +418,14 @@ struct rd_scratch {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (l.idx < 0 || (size_t)l.idx >= ents.size()) return;
-        if (failed) ents[(size_t)l.idx].dirty = true;
-        if (hipEventRecord(ents[(size_t)l.idx].done, s) != hipSuccess) ents[(size_t)l.idx].dirty = true;
+        entry &e = ents[(size_t)l.idx];
+        if (failed) e.dirty = true;
+        // The marker is what recycling asks ("has this entry's last use finished?"), and nothing is recycled while the table
+        // has room: until then the call saves itself the event (one barrier packet per render on the launch stream -- it sat
+        // between a single-frame render's last kernel and the caller's own event).
+        if (ents.size() < max_entries) { e.recorded = false; return; }
+        e.recorded = hipEventRecord(e.done, s) == hipSuccess;
+        if (!e.recorded) e.dirty = true;
     }
     void mark_all_dirty()
     {
