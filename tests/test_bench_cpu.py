@@ -177,3 +177,40 @@ def test_rank_records_gather_over_gloo_world_size_2(tmp_path):
     assert len({r["pid"] for r in g["diag"]["ranks"]}) == 2                                # two processes really reported
     n = json.load(open(tmp_path / "diag_nccl.json"))
     assert n["err"] and "under nccl every rank must own its GPU" in n["err"]
+
+
+def test_bound_measured_follows_the_runs_own_fractions():
+    """roofline.bound is declared (the roofline achieved / peak refer to); roofline.bound_measured is derived from the two
+    fractions of the run: the larger names it, within 5 % of each other both do; no VALU figure, no claim."""
+    valu = {"valu_issue_frac": 0.92}
+    assert bench.bound_measured_of(5489.2, 5938.8, valu)["bound_measured"] == "hbm+valu"          # 0.924 vs 0.92
+    assert bench.bound_measured_of(3747.7, 5938.8, {"valu_issue_frac": 0.97})["bound_measured"] == "valu"
+    assert bench.bound_measured_of(5700.0, 5750.0, {"valu_issue_frac": 0.80})["bound_measured"] == "hbm"
+    assert bench.bound_measured_of(5489.2, None, valu)["bound_measured"] in ("hbm", "hbm+valu", "valu")   # the guide's copy figure
+    assert "6290" in bench.bound_measured_of(5489.2, None, valu)["bound_measured_note"]
+    assert bench.bound_measured_of(5489.2, 5938.8, {"valu_issue_frac": None})["bound_measured"] is None
+    assert bench.bound_of("f32", 0.69, valu) == "hbm" and bench.bound_of("u8", 0.46, valu) == "valu"      # declared, as before
+
+
+def test_buffers_can_be_views_into_one_arena():
+    """--plane-stagger / --ring-arena (A/B switches, profiles/r05_plane_stagger.txt): planes and surfaces as views into one
+    allocation each, 2 MiB-aligned pitch + stagger, same contents as separate allocations; the defaults allocate separately."""
+    import numpy as np
+    import torch
+    a = bench.parse_args([])
+    assert a.plane_stagger == -1 and a.ring_arena == 0
+    ring = bench.alloc_ring(torch, "cpu", 3, 1000, arena=True)
+    ptrs = [r.data_ptr() for r in ring]
+    assert all(r.numel() == 1000 for r in ring) and ptrs[1] - ptrs[0] == ptrs[2] - ptrs[1] == 2 << 20 and ptrs[0] % (2 << 20) == 0
+    assert len({r.data_ptr() for r in bench.alloc_ring(torch, "cpu", 3, 1000)}) == 3
+
+    class FakeRa:
+        class EditParams:
+            @staticmethod
+            def random(rng):
+                return float(rng.random())
+    c0, p0 = bench.make_batch(torch, np, FakeRa, "cpu", 16, 6, 3, 0, 1)
+    c1, p1 = bench.make_batch(torch, np, FakeRa, "cpu", 16, 6, 3, 0, 1, stagger=4096)
+    assert p0 == p1 and all(torch.equal(x, y) for x, y in zip(c0, c1))
+    d = [c.data_ptr() for c in c1]
+    assert d[0] % (2 << 20) == 0 and d[1] - d[0] == (2 << 20) + 4096 == d[2] - d[1]
