@@ -2,9 +2,13 @@
 # round 5: the workgroup prologue in one phase (all table loads in flight, histogram zeroed meanwhile, one barrier) against
 # the three-phase form (tools/librawdev_r5prologue3.so = the commit before), on the launch-heavy shapes: BASELINE config 5 as
 # worded (8 row-band launches per 100 MP f16 frame), one launch per 24 MP frame (RGBA8, f16), and the single-frame render.
+# The old library is built from the parent of commit 674b3a9 ("Export kernel: one-phase workgroup prologue"):
+#   git worktree add /tmp/before 674b3a9^ && hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared \
+#       -std=c++17 -pthread -ldl -o tools/librawdev_r5prologue3.so /tmp/before/raweditor_amd/csrc/rawdev.hip
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-r5prologue}; mkdir -p "$OUT"
 OLD=$ROOT/tools/librawdev_r5prologue3.so
+[ -f "$OLD" ] || { echo "build $OLD first (see the head of this script)"; exit 1; }
 show() { python3 -c "
 import json
 d=json.load(open('$OUT/$1.json')); r=d['roofline']
