@@ -401,6 +401,26 @@ extern "C" int rd_render_device(rd_pipeline *p, uint32_t out_w, uint32_t out_h, 
 }
 RD_CATCH_INT(rd_render_device)
 
+// Both ENDS of a host range being page-locked is not enough to point a DMA engine at it: two registrations with a gap between
+// them, or a buffer that outgrew its registered window, have page-locked ends and a pageable middle.  ONE allocation or
+// registration must cover [ptr, ptr + n).  hipPointerGetAttribute's RANGE_START_ADDR / RANGE_SIZE give the base and size of
+// the runtime's memory object behind a pointer -- a hipHostMalloc / rd_host_alloc block or a hipHostRegister'ed window (what a
+// Rust host does to a Vec it wants to keep) alike (tools/probe_registered_host.py; hipMemGetAddressRange reports a NULL base
+// for a registered window, and ROCr's hsa_amd_pointer_info does not know it at all).  If the runtime cannot say, the range is
+// staged: always correct, one host copy slower.
+static bool rd_one_allocation_covers(const void *ptr, size_t n)
+{
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)ptr) != hipSuccess ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const uintptr_t lo = (uintptr_t)base, p0 = (uintptr_t)ptr;
+    return lo && p0 >= lo && p0 + n <= lo + size;
+}
+
 // Is [ptr, ptr + n) page-locked host memory the DMA engines can write (hipHostMalloc / rd_host_alloc / hipHostRegister)?
 enum { RD_MEM_PAGEABLE = 0, RD_MEM_PINNED = 1, RD_MEM_DEVICE = 2 };
 static int rd_host_memory_kind(const void *ptr, size_t n)
@@ -415,17 +435,7 @@ static int rd_host_memory_kind(const void *ptr, size_t n)
         if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return RD_MEM_DEVICE;
         if (a.type != hipMemoryTypeHost) kind = RD_MEM_PAGEABLE;       // unregistered / managed: staged
     }
-    if (kind == RD_MEM_PINNED && n > 1) {
-        // Both ENDS are page-locked; the middle must be too before a DMA engine is pointed at the range: two registrations
-        // with a gap between them, or a buffer that outgrew its registered window, would pass the test above.  One
-        // allocation (or registration) must cover [ptr, ptr + n); if the runtime cannot say, the range is staged.
-        hipDeviceptr_t base = nullptr;
-        size_t size = 0;
-        const hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
-        if (e != hipSuccess) { (void)hipGetLastError(); return RD_MEM_PAGEABLE; }
-        const uintptr_t lo = (uintptr_t)base, hi = lo + size, p0 = (uintptr_t)ptr;
-        if (!(p0 >= lo && p0 + n <= hi)) return RD_MEM_PAGEABLE;
-    }
+    if (kind == RD_MEM_PINNED && n > 1 && !rd_one_allocation_covers(ptr, n)) return RD_MEM_PAGEABLE;
     return kind;
 }
 

@@ -191,6 +191,59 @@ def test_page_locked_destinations_are_detected(gpu_lib):
     pipe.close()
 
 
+def test_registered_host_windows_and_the_gap_between_two(gpu_lib, refc):
+    """a host range whose two ENDS are page-locked but whose middle is not (two hipHostRegister windows with a
+    gap, or a buffer larger than its registered window) must not be handed to the DMA engine.  A whole registered window --
+    what a Rust host does to a Vec it keeps -- takes the direct path, any sub-range of it too; the range that spans the gap is
+    staged; and a full-resolution render into each of them gives the oracle's bytes."""
+    import ctypes as C
+    ra = gpu_lib
+    from raweditor_amd import _lib
+    L = _lib.lib()
+    path = next(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln)      # the HIP runtime this process has mapped
+    hip = C.CDLL(path)
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    hip.hipHostUnregister.argtypes = [C.c_void_p]
+    h, w = 2056, 2048                                            # a 16.1 MiB RGBA8 surface: the band-pipelined read-back
+    need = h * w * 4
+    page = 4096
+    buf = np.zeros(need + 3 * page, np.uint8)
+    base = (buf.ctypes.data + page - 1) & ~(page - 1)
+    rng = np.random.default_rng([0x52415745, 92])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = ra.RenderPipeline.new(5, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+    exp = _oracle8(refc, cfa, params).reshape(-1)
+    view = np.frombuffer((C.c_uint8 * need).from_address(base), dtype=np.uint8)
+    # (1) one window over the whole destination
+    assert L.rd_debug_is_pinned_host(C.c_void_p(base), need) == 0
+    assert hip.hipHostRegister(C.c_void_p(base), need + page, 0) == 0
+    try:
+        assert L.rd_debug_is_pinned_host(C.c_void_p(base), need) == 1
+        assert L.rd_debug_is_pinned_host(C.c_void_p(base + page), need - 2 * page) == 1
+        view[:] = 0x5a
+        pipe.render_full_res_to_bytes(out=view)
+        assert np.array_equal(view, exp), "registered window (direct DMA)"
+    finally:
+        assert hip.hipHostUnregister(C.c_void_p(base)) == 0
+    # (2) two windows, first and last megabyte, nothing in between: both ends page-locked, the middle pageable
+    mb = 1 << 20
+    last = (base + need - mb) & ~(page - 1)
+    assert hip.hipHostRegister(C.c_void_p(base), mb, 0) == 0
+    assert hip.hipHostRegister(C.c_void_p(last), mb + page, 0) == 0
+    try:
+        assert L.rd_debug_is_pinned_host(C.c_void_p(base), mb) == 1
+        assert L.rd_debug_is_pinned_host(C.c_void_p(base), need) == 0, "ends registered, middle not: must be staged"
+        assert L.rd_debug_is_pinned_host(C.c_void_p(base), mb + page) == 0, "a range that outgrows its window"
+        view[:] = 0xa5
+        pipe.render_full_res_to_bytes(out=view)
+        assert np.array_equal(view, exp), "range across the gap (staged)"
+    finally:
+        hip.hipHostUnregister(C.c_void_p(base))
+        hip.hipHostUnregister(C.c_void_p(last))
+    pipe.close()
+
+
 def test_six_threads_share_four_render_lanes(gpu_lib, refc):
     """More concurrent host renders than lanes: every call takes a lane for its duration, the fifth and sixth wait for one;
     previews, histogram renders, calculate_histogram, f32 renders with a fused histogram and band-pipelined exports all
