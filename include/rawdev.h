@@ -129,7 +129,9 @@ uint32_t rd_elided_steps(const rd_edit_params *params, const float wb_multiplier
 /* ---- RenderPipeline ------------------------------------------------------------------------ */
 /* RenderPipeline::new (pipeline.rs:114-363).  `cfa` is w*h u16, row-major, no padding
  * (raw/loader.rs:11-19); it is borrowed for the call and copied to HBM.  `color_matrix` is the
- * host's row-major [9]; like the reference the rows are consumed as COLUMNS (shaders.rs:209-214). */
+ * host's row-major [9]; like the reference the rows are consumed as COLUMNS (shaders.rs:209-214).
+ * The first pipeline a process creates on a device also builds and uploads the narrow surfaces' code tables
+ * (about 40 ms of host time, once): no later render allocates or synchronises on their account. */
 int rd_pipeline_create(int device, int64_t image_id, const uint16_t *cfa, uint32_t width,
                        uint32_t height, const rd_edit_params *params, const float wb_multipliers[4],
                        const float color_matrix[9], rd_pipeline **out);
