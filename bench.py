@@ -857,14 +857,17 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
                                      f"the reference's own surface (Rgba8Unorm, pipeline.rs:322) on the batch workload: {n8} x 6016x4016, "
                                      "randomised stacks, fused histogram, strict f32 arithmetic", "multi", valu_ns=valu_ns)
     W5, H5 = 11648, 8736
-    c5, p5 = make_batch(torch, np, ra, dev, W5, H5, 16, 1 << 20, 1)
-    out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 6, stream,
-                                           "BASELINE configs[4] shape on one GPU: 16 x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
+    # BASELINE configs[4] is 512 frames over 8 GPUs = 64 per GPU: that many when the headline batch is the full one
+    # (13 GB of planes + a ring of 4 surfaces; the reduced batches of the tests keep 16)
+    n5 = 64 if len(cfas) >= 256 else 16
+    c5, p5 = make_batch(torch, np, ra, dev, W5, H5, n5, 1 << 20, 1)
+    out["config5_shape_f16"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3 if n5 > 16 else 6, stream,
+                                           f"BASELINE configs[4]'s per-GPU share on one GPU: {n5} x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
                                            "randomised stacks, fused histogram, strict f32 arithmetic; default launch mode: multi-frame "
                                            "launches (4 frames each, capped by the ring of 4), which sweep a frame in row order and "
                                            "need no row bands of their own", "multi", valu_ns=valu_ns)
-    out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 3, stream,
-                                                 "the same 16 x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
+    out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 2 if n5 > 16 else 3, stream,
+                                                 f"the same {n5} x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
                                                  "8 row-band launches per frame (RD_BATCH_PERSISTENT=0), alternating between two streams (RD_BATCH_STREAMS=2)", "per_frame", tiled=True)
     del c5
     out["ragged_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
