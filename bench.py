@@ -66,7 +66,7 @@ def parse_args(argv=None):
                          "histogram all-reduce happens inside librawdev over RCCL)")
     ap.add_argument("--static-descriptors", action="store_true",
                     help="resubmit ONE frame array every step (librawdev then skips the descriptor upload); default: the "
-                         "steps alternate between two arrays so every step uploads its descriptors")
+                         "steps rotate through three arrays so every step uploads its descriptors")
     ap.add_argument("--no-alt-math", action="store_true",
                     help="skip the short extra run in the other math mode (reported under 'alt_math', N=1 only)")
     ap.add_argument("--no-extra", action="store_true", help="skip 'extra_configs' (config 1, RGBA8, config-5 shape; N=1 only)")
@@ -483,6 +483,16 @@ def swapped_halves(params):
     return [params[(i + n // 2) % n] for i in range(n)] if n > 1 else list(params)
 
 
+def rotated_stacks(params, k, m=3):
+    """The same stacks, rotated by k/m of the batch: different descriptors, identical total arithmetic.  Three arrays in
+    rotation defeat librawdev's descriptor cache (it keeps the last TWO arrays it was given and skips the upload when a call
+    repeats one of them): round 5 found that rounds 3-4's "two alternating arrays" were both cached after the second step,
+    so no step of their timed regions uploaded anything."""
+    n = len(params)
+    r = (k * n) // m
+    return [params[(i + r) % n] for i in range(n)] if n > 1 else list(params)
+
+
 def workload_label(W, H, world, F):
     if (W, H) == (6016, 4016):
         return "BASELINE configs[2]" if world == 1 else f"BASELINE configs[3] ({F} frames per GPU)"
@@ -635,19 +645,19 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
                 os.environ.pop(k, None)
                 if v is not None:
                     os.environ[k] = v
-    variants = [params, swapped_halves(params)]
+    variants = [rotated_stacks(params, k) for k in range(3)]
     arrays = [be.make_frames([c.data_ptr() for c in cfas], [ring[i % ring_n].data_ptr() for i in range(F)], v, WB, CM)
               for v in variants]
     with torch.cuda.stream(stream):
         k = 0
         for _ in range(2):
-            be.develop(arrays[k % 2], row_bands=row_bands, stream=stream.cuda_stream); k += 1
+            be.develop(arrays[k % 3], row_bands=row_bands, stream=stream.cuda_stream); k += 1
         be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
         stream.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(steps):
-            be.develop(arrays[k % 2], row_bands=row_bands, stream=stream.cuda_stream); k += 1
+            be.develop(arrays[k % 3], row_bands=row_bands, stream=stream.cuda_stream); k += 1
             be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
         e1.record(stream)
         stream.synchronize()
@@ -657,7 +667,7 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     ok = int(hist.sum().item()) == 3 * F * W * H
     note = "histogram does not count every pixel"
     if ok:
-        ok, note = verify_outputs(fmt_name, W, H, cfas, variants[(k - 1) % 2], ring, F, "strict")
+        ok, note = verify_outputs(fmt_name, W, H, cfas, variants[(k - 1) % 3], ring, F, "strict")
     be.close()
     del ring
     return {"config": label, "frames": F, "steps": steps, "ms": round(ms / steps, 4), "us_per_frame": round(us, 2),
@@ -924,7 +934,7 @@ def run_ranks(args):
 
     math_mode = ra.MATH_CONTRACTED if args.math == "contracted" else ra.MATH_STRICT
     be = ra.BatchExporter(dev_index, W, H, fmt, with_hist, math_mode=math_mode)
-    variants = [params] if args.static_descriptors else [params, swapped_halves(params)]
+    variants = [params] if args.static_descriptors else [rotated_stacks(params, k) for k in range(3)]
     arrays = [be.make_frames([c.data_ptr() for c in cfas], [ring[i % len(ring)].data_ptr() for i in range(F)], v, WB, CM)
               for v in variants]
     stream = torch.cuda.Stream(device=dev)
@@ -999,8 +1009,8 @@ def run_ranks(args):
     result = result_line(args, world, F, W, H, elapsed, dev_ms, lpc, len(ring), verified, verified_note,
                          "one process per GPU (torch.distributed, backend " + (backend if world > 1 else "none: single rank") + ")" + unmeasured,
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
-                         "steps alternate between two frame arrays (slider stacks of the two batch halves swapped): every step "
-                         "uploads its descriptors", box=box, valu_ns=valu_ns)
+                         "steps rotate through three frame arrays (the slider stacks rotated by a third of the batch); librawdev caches "
+                         "the last two arrays it saw, so every step uploads its descriptors", box=box, valu_ns=valu_ns)
     if rank == 0:
         # as-nccl: the duplicate-device rule applies to this run (nccl always; RAWDEV_DIAG_ASSUME_NCCL=1 lets the gloo
         # rehearsal on a one-GPU box prove that the rule fires)
@@ -1126,11 +1136,11 @@ def run_node(args):
         for i in range(F * N):
             r, f = i % N, i // N
             cfas, params, ring = per_dev[r]
-            pv = swapped_halves(params) if swap else params
+            pv = rotated_stacks(params, swap)
             cp.append(cfas[f].data_ptr()); op.append(ring[f % len(ring)].data_ptr()); pp.append(pv[f])
         return ra.BatchExporter.make_frames(cp, op, pp, WB, CM)
 
-    arrays = [frame_array(False)] if args.static_descriptors else [frame_array(False), frame_array(True)]
+    arrays = [frame_array(0)] if args.static_descriptors else [frame_array(k) for k in range(3)]
     nstep = [0]
     hist = None
 
@@ -1174,7 +1184,7 @@ def run_node(args):
     verified, verified_note = None, "not checked"
     try:
         cfas, params, ring = per_dev[0]
-        last = params if (len(arrays) == 1 or (nstep[0] - 1) % 2 == 0) else swapped_halves(params)
+        last = rotated_stacks(params, (nstep[0] - 1) % len(arrays))
         verified, verified_note = verify_outputs(args.format, W, H, cfas, last, ring, F, args.math)
     except Exception as e:  # noqa: BLE001
         verified, verified_note = None, f"oracle check unavailable: {e}"
@@ -1185,7 +1195,7 @@ def run_node(args):
                          f"histogram reduction: {nb.reduce_kind()}; each step = develop + histogram " + ("(synchronises)" if drain else "fold / all-reduce / read-back enqueued (no drain between steps)") +
                          ("; REHEARSAL: a device is listed more than once, the ranks share one GPU" if dup else ""),
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
-                         "steps alternate between two frame arrays: every step uploads its descriptors", box=box)
+                         "steps rotate through three frame arrays (librawdev caches two): every step uploads its descriptors", box=box)
     result["devices"] = [{"slot": i, "device_index": d, "pci_bus_id": idents[i].get("pci_bus_id"), "name": idents[i].get("name"),
                           "launches": nb.last_launch_count(i) * args.steps} for i, d in enumerate(devices)]
     result["distinct_devices"] = len({(i.get("pci_bus_id") or f"index:{d}") for i, d in zip(idents, devices)})

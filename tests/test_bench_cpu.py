@@ -39,6 +39,25 @@ def test_swapped_halves_is_a_permutation_that_changes_every_descriptor():
     assert bench.swapped_halves([5]) == [5]
 
 
+def test_three_rotated_arrays_defeat_a_two_entry_descriptor_cache():
+    """librawdev keeps the last two frame arrays it was given and skips the upload when a call repeats one (rd_host_batch.inl);
+    bench.py's steps therefore rotate through THREE arrays (round 5: two alternating ones were both cached after the second
+    step).  The rotations are permutations of the same stacks, pairwise different in every position, and in a rotation of
+    three no step's array equals either of the two before it."""
+    p = list(range(12))
+    v = [bench.rotated_stacks(p, k) for k in range(3)]
+    assert v[0] == p and all(sorted(x) == p for x in v)
+    for a in range(3):
+        for b in range(a + 1, 3):
+            assert all(x != y for x, y in zip(v[a], v[b]))
+    cache = []                                                    # a two-entry cache, as the library keeps it
+    for step in range(9):
+        cur = v[step % 3]
+        assert cur not in cache, "a cached array: no upload would happen"
+        cache = (cache + [cur])[-2:]
+    assert bench.rotated_stacks([7], 2) == [7]
+
+
 def _fake_rank_script(tmp_path, fail_rank=None):
     script = tmp_path / "fake_rank.py"
     script.write_text(textwrap.dedent(f"""
