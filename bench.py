@@ -7,9 +7,21 @@ uniform 12-bit, seed 0x52415745) resident in HBM, one randomised slider stack pe
 the UI ranges, wb = (2, 1, 1.5), non-identity colour matrix, RGBA-f32 surface written to a ring of
 output buffers, fused 3x256 histogram accumulated in u64.  One "step" = one pass over the batch:
 the fused launches of rd_batch_develop (up to 8 frames each) + the histogram fold (+ one RCCL
-all-reduce of 768 x i64 when N > 1).  Consecutive steps submit DIFFERENT frame descriptors (the
-slider stacks of the two halves of the batch are swapped every other step), so every step pays the
-descriptor upload a real export pays (--static-descriptors restores the resubmission of one array).
+all-reduce of 768 x i64 when N > 1).  Consecutive steps submit DIFFERENT frame descriptors: the
+steps rotate through THREE frame arrays (the slider stacks rotated by 0, 1/3 and 2/3 of the batch;
+librawdev caches the last two arrays it saw), so every step pays the descriptor upload a real
+export pays (--static-descriptors restores the resubmission of one array).
+
+The line explains its own speed (round 6).  After the timed region, outside it: an instrumented
+pass with a HIP event pair around every fused launch (`roofline.launches`: launch_us_by_position,
+min / median / max, `kernel_ms_per_step`, `gap_ms_per_step`, `roofline.frac_kernel`), the shader
+clock the part holds UNDER the kernel (`clock_under_kernel_GHz`: cycle / real-time stamps of a
+diagnostic kernel instance), board clocks / power / temperature while the same steps run
+(`clocks`: amdsmi, else sysfs, else null with the reason), the box probes before AND after the
+region (`roofline.box_before` / `box_after`), the same launches with the kernel's arithmetic
+removed on the same buffers (`roofline.box_pattern_GBps`, `frac_of_box_pattern`: the memory
+pattern's own ceiling on this box), and an alternating A/B of rotating against static descriptors
+(`descriptor_upload_ab`).  --no-diagnose skips all of it.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus N ...                     # N > 1 without a launcher: starts N rank processes itself
@@ -80,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--data", choices=["uniform", "gradient"], default="uniform",
                     help="uniform: i.i.d. 12-bit samples (SURVEY 8d, the headline); gradient: smooth ramp + 1 %% noise "
                          "(SURVEY 8d's second distribution: flat regions, same-bin histogram atomics, less bit toggling)")
+    ap.add_argument("--no-diagnose", action="store_true",
+                    help="skip the self-diagnosis after the timed region (per-launch event pairs, clock under the kernel, board clocks, "
+                         "box probes after the region, pattern probe, descriptor A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     return ap.parse_args(argv)
@@ -88,13 +103,80 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` with N > 1 and no launcher environment
 # ------------------------------------------------------------------------------------------------
-def child_env(base_env, rank, world, port):
-    """Environment of rank `rank` of `world` single-node rank processes (what torch.distributed.run would export)."""
+VISIBILITY_VARS = ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")     # in the order the stack applies them
+
+
+def physical_gpu_count():
+    """GPUs of this machine WITHOUT touching HIP or torch.cuda: the KFD topology nodes that have SIMDs (CPU nodes have none).
+    0 when the topology cannot be read (no driver: this container)."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(path):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def narrow_visibility(env, local_rank, n_gpus=None):
+    """One process per GPU, and every process sees ONLY its own GPU (the rule of round 6).
+
+    `python -m torch.distributed.run --nproc-per-node N bench.py` starts N ranks that each see all N cards, and the first HIP
+    call of every rank opens every card it sees: N processes on each GPU.  The pool's boxes kill a run with more than six
+    processes on a card (the six-rank rehearsal of round 5 died that way), so before anything touches the GPU a rank narrows
+    its own view to the card it will use -- the LOCAL_RANK-th entry of the visibility list that is already set
+    (ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES, whichever the stack applies first), or ROCR_VISIBLE_DEVICES=<LOCAL_RANK> when none
+    is -- and then uses device index 0.  A list with one entry is a launcher that has narrowed already: left alone.  With more
+    ranks than cards (a gloo rehearsal on a one-GPU box) the entry is taken modulo the number of cards.
+    RAWDEV_RANK_VISIBILITY=all keeps every card visible to every rank (rank r then uses index r): the usual torchrun
+    arrangement, for a node whose RCCL refuses peers it cannot see.  The one-process host (`--host node`) is the fallback
+    that puts exactly one process on every card whatever the launcher does.
+    Mutates `env`; returns what it did (it goes into the bench line)."""
+    mode = (env.get("RAWDEV_RANK_VISIBILITY") or "own").strip().lower()
+    info = {"mode": mode, "variable": None, "value": None, "local_rank": local_rank}
+    if mode != "own":
+        info["note"] = "RAWDEV_RANK_VISIBILITY=%s: every rank sees every card the launcher shows it" % mode
+        return info
+    if env.get("RAWDEV_RANK_NARROWED") == "1":               # the self-launcher (child_env) has done it for this process
+        for var in VISIBILITY_VARS:
+            if env.get(var):
+                info.update(variable=var, value=env[var])
+                break
+        info["note"] = "narrowed by the launcher (child_env)"
+        return info
+    for var in VISIBILITY_VARS:
+        items = [x.strip() for x in (env.get(var) or "").split(",") if x.strip()]
+        if not items:
+            continue
+        if len(items) == 1:
+            info.update(variable=var, value=items[0], note="the launcher shows this rank one device already")
+            return info
+        env[var] = items[local_rank % len(items)]
+        info.update(variable=var, value=env[var], note="entry %d of the launcher's list of %d" % (local_rank % len(items), len(items)))
+        env["RAWDEV_RANK_NARROWED"] = "1"
+        return info
+    n = physical_gpu_count() if n_gpus is None else n_gpus
+    idx = local_rank % n if n > 0 else local_rank
+    env["ROCR_VISIBLE_DEVICES"] = str(idx)
+    env["RAWDEV_RANK_NARROWED"] = "1"
+    info.update(variable="ROCR_VISIBLE_DEVICES", value=str(idx), physical_gpus=n,
+                note="no visibility list was set: card LOCAL_RANK" + (" modulo the machine's %d" % n if n > 0 else ""))
+    return info
+
+
+def child_env(base_env, rank, world, port, n_gpus=None):
+    """Environment of rank `rank` of `world` single-node rank processes (what torch.distributed.run would export), narrowed
+    to the rank's own GPU (narrow_visibility) unless RAWDEV_RANK_VISIBILITY=all."""
     env = dict(base_env)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GROUP_RANK": "0", "ROLE_RANK": str(rank)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what this pool's host driver supports
     env.setdefault("OMP_NUM_THREADS", "1")
+    env.pop("RAWDEV_RANK_NARROWED", None)
+    narrow_visibility(env, rank, n_gpus)
     return env
 
 
@@ -315,7 +397,8 @@ def pmc_traffic(fmt_name, W, H, mode):
 # interactively, so its line must say by itself which devices the ranks were on and how each of them did)
 # ------------------------------------------------------------------------------------------------
 DIAG_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "NCCL_DEBUG",
-            "RCCL_MSCCL_ENABLE", "NCCL_SOCKET_IFNAME", "NCCL_P2P_DISABLE", "RAWDEV_DIST_BACKEND", "RD_BATCH_MAX_FRAMES", "RD_BATCH_PERSISTENT")
+            "RCCL_MSCCL_ENABLE", "NCCL_SOCKET_IFNAME", "NCCL_P2P_DISABLE", "RAWDEV_DIST_BACKEND", "RAWDEV_RANK_VISIBILITY", "RD_BATCH_MAX_FRAMES",
+            "RD_BATCH_PERSISTENT")
 
 
 def rank_record(rank, local_rank, dev_index, ident, elapsed_s, dev_ms, steps, frames, width, height, launches_per_step, box):
@@ -389,6 +472,208 @@ def measure_valu_ns(ra, dev_index):
         return ra.measure_valu(dev_index)
     except Exception:  # noqa: BLE001
         return None
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return 0.0 if not n else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+def launch_summary(timeline, alg_bytes_per_launch=None):
+    """[(call, start_us, end_us), ...] of rd_batch_launch_timeline -> what the launches of a step cost, by position in
+    the step (a step = one develop call; the median over the kept calls), and what lies between them."""
+    calls = {}
+    for c, st, en in timeline:
+        calls.setdefault(c, []).append((st, en))
+    keys = sorted(calls)
+    if not keys:
+        return None
+    npos = min(len(calls[k]) for k in keys)
+    by_pos = [_median([calls[k][i][1] - calls[k][i][0] for k in keys]) for i in range(npos)]
+    durs = [en - st for _, st, en in timeline]
+    inner = [calls[k][i][0] - calls[k][i - 1][1] for k in keys for i in range(1, len(calls[k]))]
+    boundary = [calls[keys[j]][0][0] - calls[keys[j - 1]][-1][1] for j in range(1, len(keys))]
+    period = [calls[keys[j]][0][0] - calls[keys[j - 1]][0][0] for j in range(1, len(keys))]
+    out = {"steps": len(keys), "launches_per_step": npos,
+           "launch_us_by_position": [round(x, 1) for x in by_pos],
+           "launch_us": {"min": round(min(durs), 1), "median": round(_median(durs), 1), "max": round(max(durs), 1),
+                         "mean": round(sum(durs) / len(durs), 1)},
+           "kernel_ms_per_step": round(sum(by_pos) / 1e3, 4),
+           "gap_us_between_launches": {"median": round(_median(inner), 2), "max": round(max(inner), 2)} if inner else None,
+           "step_boundary_gap_us": {"median": round(_median(boundary), 1), "max": round(max(boundary), 1)} if boundary else None,
+           "instrumented_ms_per_step": round(_median(period) / 1e3, 4) if period else None,
+           "note": "an untimed pass AFTER the timed region with a HIP event pair around every fused launch (rd_batch_set_launch_timing): "
+                   "launch_us_by_position = median over the steps of each launch's own duration; step_boundary_gap_us = last launch of a "
+                   "step -> first launch of the next (histogram fold, all-reduce when N > 1, descriptor upload and the event packets); "
+                   "the pairs put two barrier packets between launches, so instrumented_ms_per_step is not the timed region's figure"}
+    if alg_bytes_per_launch:
+        out["GBps_median_launch"] = round(alg_bytes_per_launch / (_median(durs) * 1e-6) / 1e9, 1)
+    return out
+
+
+def instrumented_pass(be, step_fn, sync_fn, n_steps, alg_bytes_per_launch=None):
+    """n_steps of the caller's step with an event pair around every launch; None when the library refuses."""
+    try:
+        be.set_launch_timing(n_steps)
+        for _ in range(n_steps):
+            step_fn()
+        sync_fn()
+        tl = be.launch_timeline()
+        be.set_launch_timing(0)
+        return launch_summary(tl, alg_bytes_per_launch)
+    except Exception as e:  # noqa: BLE001  (a diagnosis must not cost the line)
+        try:
+            be.set_launch_timing(0)
+        except Exception:  # noqa: BLE001
+            pass
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+# ------------------------------------------------------------------------------------------------
+# board clocks / power / temperature while the workload runs (amdsmi if it initialises, else sysfs, else the reason)
+# ------------------------------------------------------------------------------------------------
+def _num(v):
+    return v if isinstance(v, (int, float)) and not isinstance(v, bool) and 0 < v < 65535 else None
+
+
+def open_clock_source(pci_bus_id):
+    """-> (sample() -> {name: number}, source text) or (None, why not).  Never a new dependency: amdsmi is imported only
+    if this image ships it, and every call is allowed to fail."""
+    reasons = []
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        handles = list(amdsmi.amdsmi_get_processor_handles())
+        h = None
+        for cand in handles:
+            try:
+                if pci_bus_id and str(amdsmi.amdsmi_get_gpu_device_bdf(cand)).lower() == pci_bus_id.lower():
+                    h = cand
+            except Exception:  # noqa: BLE001
+                continue
+        if h is None and len(handles) == 1:
+            h = handles[0]
+        if h is None:
+            raise RuntimeError(f"{len(handles)} amdsmi handles, none with BDF {pci_bus_id}")
+        gfx_type = getattr(amdsmi.AmdSmiClkType, "GFX", amdsmi.AmdSmiClkType.SYS)
+
+        def sample():
+            out = {}
+            try:
+                m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                xs = [x for x in (m.get("current_gfxclks") or []) if _num(x)]
+                if xs:
+                    out["sclk_MHz"] = _median(xs)
+                for src, dst in (("current_gfxclk", "sclk_MHz"), ("current_uclk", "mclk_MHz"), ("current_socket_power", "power_W"),
+                                 ("average_socket_power", "power_W"), ("temperature_hotspot", "temp_hotspot_C"),
+                                 ("temperature_mem", "temp_mem_C"), ("average_gfx_activity", "gfx_activity_pct"),
+                                 ("average_umc_activity", "mem_activity_pct")):
+                    if dst not in out and _num(m.get(src)) is not None:
+                        out[dst] = m[src]
+            except Exception:  # noqa: BLE001
+                pass
+            for dst, fn in (("sclk_MHz", lambda: amdsmi.amdsmi_get_clock_info(h, gfx_type).get("clk")),
+                            ("mclk_MHz", lambda: amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.MEM).get("clk")),
+                            ("power_W", lambda: (lambda d: d.get("current_socket_power") if _num(d.get("current_socket_power")) else d.get("average_socket_power"))(amdsmi.amdsmi_get_power_info(h))),
+                            ("temp_hotspot_C", lambda: amdsmi.amdsmi_get_temp_metric(h, amdsmi.AmdSmiTemperatureType.HOTSPOT, amdsmi.AmdSmiTemperatureMetric.CURRENT))):
+                if dst in out:
+                    continue
+                try:
+                    v = fn()
+                    if _num(v) is not None:
+                        out[dst] = v
+                except Exception:  # noqa: BLE001
+                    pass
+            return out
+        if not sample():
+            raise RuntimeError("amdsmi initialised but returned no clock / power / temperature metric")
+        return sample, "amdsmi"
+    except Exception as e:  # noqa: BLE001
+        reasons.append(f"amdsmi: {type(e).__name__}: {' '.join(str(e).split())[:160]}")
+    try:
+        import glob
+        dev = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                ue = open(os.path.join(d, "uevent")).read()
+            except OSError:
+                continue
+            if pci_bus_id and f"PCI_SLOT_NAME={pci_bus_id}".lower() in ue.lower():
+                dev = d
+        if dev is None:
+            raise RuntimeError(f"no /sys/class/drm/card*/device with PCI_SLOT_NAME={pci_bus_id}")
+
+        def dpm(name):
+            for line in open(os.path.join(dev, name)).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            return None
+
+        def first(patterns, scale):
+            for pat in patterns:
+                for f in sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*", pat))):
+                    try:
+                        return float(open(f).read().strip()) * scale
+                    except (OSError, ValueError):
+                        continue
+            return None
+
+        def sample():
+            out = {}
+            for dst, fn in (("sclk_MHz", lambda: dpm("pp_dpm_sclk")), ("mclk_MHz", lambda: dpm("pp_dpm_mclk")),
+                            ("power_W", lambda: first(("power1_input", "power1_average"), 1e-6)),
+                            ("temp_hotspot_C", lambda: first(("temp2_input", "temp1_input"), 1e-3))):
+                try:
+                    v = fn()
+                    if _num(v) is not None:
+                        out[dst] = v
+                except Exception:  # noqa: BLE001
+                    pass
+            return out
+        if not sample():
+            raise RuntimeError("sysfs files present but unreadable")
+        return sample, "sysfs (/sys/class/drm/card*/device: pp_dpm_sclk, pp_dpm_mclk, hwmon)"
+    except Exception as e:  # noqa: BLE001
+        reasons.append(f"sysfs: {type(e).__name__}: {' '.join(str(e).split())[:160]}")
+    return None, "; ".join(reasons)
+
+
+class ClockSampler:
+    """Samples the source every few milliseconds on a thread while the caller keeps the GPU busy (the librawdev calls
+    release the GIL)."""
+
+    def __init__(self, sample_fn, period_s=0.004):
+        import threading
+        self.fn, self.period, self.rows = sample_fn, period_s, []
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                r = self.fn()
+                if r:
+                    self.rows.append(r)
+            except Exception:  # noqa: BLE001
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=2.0)
+        return False
+
+    def summary(self):
+        out = {"samples": len(self.rows)}
+        for k in sorted({k for r in self.rows for k in r}):
+            xs = [r[k] for r in self.rows if k in r]
+            out[k] = {"median": round(_median(xs), 1), "min": round(min(xs), 1), "max": round(max(xs), 1)}
+        return out
 
 
 def valu_fields(fmt_name, W, H, us_per_frame, valu_ns, n_simd=1024):
@@ -502,7 +787,7 @@ def workload_label(W, H, world, F):
 
 
 def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, verified_note, host_note, descriptors_note, box=None,
-                valu_ns=None):
+                valu_ns=None, diag=None):
     total_px = float(world) * F * W * H * args.steps
     launches = args.steps * lpc
     launch_us = dev_ms * 1e3 / launches                    # avg fused-launch period incl. gaps and folds
@@ -513,7 +798,25 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
     per_frame, traffic_source = pmc_traffic(args.format, W, H, "multi" if multi else "per_frame")
     traffic = int(per_frame * F / lpc) if per_frame is not None else None       # per launch, like `achieved`
     box = box or {}
+    diag = diag or {}
     valu = valu_fields(args.format, W, H, frame_us, valu_ns)
+    ms_per_step = elapsed * 1e3 / args.steps
+    launches = diag.get("launches") if isinstance(diag.get("launches"), dict) else None
+    kernel_ms = (launches or {}).get("kernel_ms_per_step")
+    med_us = ((launches or {}).get("launch_us") or {}).get("median")
+    pattern = diag.get("pattern") if isinstance(diag.get("pattern"), dict) else None
+    pattern_GBps = (pattern or {}).get("GBps")
+
+    def ghz(ns):
+        return round(2.0 / ns, 3) if ns else None
+    box_before = dict({k: box.get(k) for k in ("copy", "fill", "read", "memset")}, valu_ns_per_full_rate_instruction=diag.get("valu_before_ns"),
+                      valu_effective_GHz=ghz(diag.get("valu_before_ns")))
+    ba = diag.get("box_after") or {}
+    box_after = dict({k: ba.get(k) for k in ("copy", "fill", "read", "memset")},
+                     valu_ns_per_full_rate_instruction=diag.get("valu_after_ns"), valu_effective_GHz=ghz(diag.get("valu_after_ns")),
+                     valu_effective_GHz_after_the_probes=ghz(diag.get("valu_after_probes_ns")),
+                     note="valu_*: rd_measure_valu right after the timed region (the clocks are up); copy / fill / read / memset: rd_measure_hbm "
+                          "after the diagnostic passes that follow it")
     return {
         "metric": "megapixels/sec through demosaic+10-slider pipeline; 24MP batch",
         "value": round(total_px / 1e6 / elapsed, 1),
@@ -521,7 +824,13 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "ms_per_step": round(ms_per_step, 4),
+        # where a step's time goes: the sum of its launches' own durations (instrumented pass after the region) and the rest
+        "kernel_ms_per_step": kernel_ms,
+        "gap_ms_per_step": round(ms_per_step - kernel_ms, 4) if kernel_ms else None,
+        "clock_under_kernel_GHz": diag.get("clock_under_kernel"),
+        "clocks": diag.get("clocks"), "clocks_reason": diag.get("clocks_reason"),
+        "descriptor_upload_ab": diag.get("descriptor_upload_ab"),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -557,6 +866,15 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
             "launch_us_note": "HIP-event time of the timed region / fused launches: an average launch PERIOD that "
                               "includes inter-launch gaps, descriptor uploads and the histogram folds (conservative)",
             "algorithmic_bytes_per_launch": int(alg_bytes),
+            # the same fraction from the MEDIAN launch's own duration (event pair around each launch, instrumented pass): what
+            # the kernel does when nothing stands between launches; `frac` above is the timed region's average launch PERIOD
+            "frac_kernel": round(alg_bytes / (med_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if med_us else None,
+            "launches": launches if launches is not None else diag.get("launches"),
+            "box_before": box_before, "box_after": box_after,
+            # the memory pattern's own ceiling: this kernel's launches with the arithmetic removed, same buffers (rd_batch_probe_pattern)
+            "box_pattern_GBps": pattern_GBps,
+            "frac_of_box_pattern": round(achieved / pattern_GBps, 4) if pattern_GBps else None,
+            "box_pattern": pattern if pattern is not None else diag.get("pattern"),
         },
     }
 
@@ -624,7 +942,7 @@ def extra_single_frame(torch, np, ra, dev, dev_index, cfa_t, p, stream, iters=60
 
 
 def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, ring_n, row_bands, steps, stream, label, kernel_mode,
-                tiled=False, valu_ns=None):
+                tiled=False, valu_ns=None, launch_diag=False):
     """A batch workload on another surface format / frame size, timed like the headline (HIP events, descriptors alternate).
     tiled: RD_BATCH_PERSISTENT=0 for this context -- every frame is `row_bands` separate row-band launches (BASELINE
     config 5's "tiled multi-launch per frame"); by default the multi-frame launch needs no bands of its own and ignores them."""
@@ -664,6 +982,17 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     ms = e0.elapsed_time(e1)
     us = ms * 1e3 / (steps * F)
     lpc = max(1, be.last_launch_count())
+    launches = None
+    if launch_diag:                                          # the same per-launch account as the headline's (outside the timed steps)
+        kk = [k]
+
+        def one_step():
+            be.develop(arrays[kk[0] % 3], row_bands=row_bands, stream=stream.cuda_stream)
+            kk[0] += 1
+            be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            launches = instrumented_pass(be, one_step, stream.synchronize, 4, BYTES_PER_PX[fmt_name] * W * H * F / lpc)
+        k = kk[0]
     ok = int(hist.sum().item()) == 3 * F * W * H
     note = "histogram does not count every pixel"
     if ok:
@@ -675,6 +1004,9 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
             # what ran: the multi-frame launch sweeps a frame in row order and cuts no bands of its own
             "row_bands_effective": row_bands if lpc >= F * max(1, row_bands) else 1,
             "frames_per_launch": round(F / lpc, 3),
+            "kernel_ms_per_step": (launches or {}).get("kernel_ms_per_step"),
+            "gap_ms_per_step": round(ms / steps - launches["kernel_ms_per_step"], 4) if (launches or {}).get("kernel_ms_per_step") else None,
+            "launches": launches,
             "roofline": roofline_of(fmt_name, W, H, us, kernel_mode, "rd_develop_quads" if lpc >= F else "rd_develop_batch", valu_ns),
             "verified": bool(ok), "verified_note": note}
 
@@ -865,7 +1197,7 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
     n8 = len(cfas)
     out["batch_rgba8"] = extra_batch(torch, np, ra, dev, dev_index, "u8", cfas[:n8], params[:n8], 6016, 4016, 32, 1, 6, stream,
                                      f"the reference's own surface (Rgba8Unorm, pipeline.rs:322) on the batch workload: {n8} x 6016x4016, "
-                                     "randomised stacks, fused histogram, strict f32 arithmetic", "multi", valu_ns=valu_ns)
+                                     "randomised stacks, fused histogram, strict f32 arithmetic", "multi", valu_ns=valu_ns, launch_diag=True)
     W5, H5 = 11648, 8736
     # BASELINE configs[4] is 512 frames over 8 GPUs = 64 per GPU: that many when the headline batch is the full one
     # (13 GB of planes + a ring of 4 surfaces; the reduced batches of the tests keep 16)
@@ -875,7 +1207,7 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
                                            f"BASELINE configs[4]'s per-GPU share on one GPU: {n5} x 11648x8736 (100 MP) frames, RGBA-f16 surface, "
                                            "randomised stacks, fused histogram, strict f32 arithmetic; default launch mode: multi-frame "
                                            "launches (4 frames each, capped by the ring of 4), which sweep a frame in row order and "
-                                           "need no row bands of their own", "multi", valu_ns=valu_ns)
+                                           "need no row bands of their own", "multi", valu_ns=valu_ns, launch_diag=True)
     out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 2 if n5 > 16 else 3, stream,
                                                  f"the same {n5} x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
                                                  "8 row-band launches per frame (RD_BATCH_PERSISTENT=0), alternating between two streams (RD_BATCH_STREAMS=2)", "per_frame", tiled=True)
@@ -897,6 +1229,8 @@ def run_ranks(args):
     # RCCL / device-tensor sharing across processes needs dmabuf IPC on this pool's host driver (already exported by the
     # image; kept here so that a bare `python -m torch.distributed.run ... bench.py` works from any shell)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one process per GPU AND one GPU per process: narrowed BEFORE torch / HIP are imported or anything touches a card
+    visibility = narrow_visibility(os.environ, local_rank) if world > 1 else {"mode": "single rank: untouched"}
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -906,8 +1240,9 @@ def run_ranks(args):
     # histogram all-reduce goes over gloo (RCCL refuses two ranks on one device).  The driver's runs use nccl.
     backend = os.environ.get("RAWDEV_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
-    # nccl: one GPU per rank.  A launcher that narrows each rank's view to one device (HIP_VISIBLE_DEVICES per rank) leaves
-    # index 0 as that rank's own GPU; whether two ranks ended up on ONE physical device is checked from the PCI bus ids below.
+    # nccl: one GPU per rank.  With the rank's view narrowed to its own card (narrow_visibility above, or a launcher that did
+    # it) one device is visible and index 0 is that card; with every card visible rank r uses index r.  Whether two ranks ended
+    # up on ONE physical device is checked from the PCI bus ids below.
     dev_index = local_rank if local_rank < ndev else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -927,6 +1262,16 @@ def run_ranks(args):
 
     ident = device_identity(dev_index)
     box = measure_box(ra, dev_index) if not args.no_box else {}       # before the headline, outside its timed region (~0.1 s)
+    valu_before = measure_valu_ns(ra, dev_index) if (rank == 0 and not args.no_box) else None
+    clock_fn, clock_src = (None, "skipped (--no-diagnose)")
+    clocks_idle = None
+    if rank == 0 and not args.no_diagnose:
+        clock_fn, clock_src = open_clock_source(ident.get("pci_bus_id"))
+        if clock_fn:
+            try:
+                clocks_idle = {k: round(v, 1) for k, v in clock_fn().items()}
+            except Exception:  # noqa: BLE001
+                clocks_idle = None
     cfas, params = make_batch(torch, np, ra, dev, W, H, F, rank, world, args.data, stagger=args.plane_stagger)     # frame i -> rank i mod N
     ring = alloc_ring(torch, dev, max(1, args.ring), H * W * bpp_out, arena=bool(args.ring_arena))
     hist = torch.zeros(768, dtype=torch.int64, device=dev)
@@ -940,9 +1285,16 @@ def run_ranks(args):
     stream = torch.cuda.Stream(device=dev)
     nstep = [0]
 
-    def step():
-        be.develop(arrays[nstep[0] % len(arrays)], row_bands=args.row_bands, stream=stream.cuda_stream)
-        nstep[0] += 1
+    def step(develop=None, array=None):
+        """One step: the fused launches of one develop call over the batch + the histogram fold (+ the all-reduce).  `develop`
+        replaces be.develop for the diagnostic passes (same frames, same order); `array` pins the frame array (descriptor A/B)."""
+        arr = array if array is not None else arrays[nstep[0] % len(arrays)]
+        if develop is None:
+            be.develop(arr, row_bands=args.row_bands, stream=stream.cuda_stream)
+        else:
+            develop(arr)
+        if array is None:
+            nstep[0] += 1
         if with_hist:
             be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
             if world > 1:
@@ -974,19 +1326,77 @@ def run_ranks(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    lpc = max(1, be.last_launch_count())
 
-    # every rank's own account of the region, gathered on rank 0 (N = 1: the one record)
-    mine = rank_record(rank, local_rank, dev_index, ident, elapsed_own, dev_ms, args.steps, F, W, H, max(1, be.last_launch_count()), box)
-    records, diag_err = [mine], None
-    world_seen = 1
-    if world > 1:
-        world_seen = dist.get_world_size()
-        try:
-            gathered = [None] * world_seen
-            dist.all_gather_object(gathered, mine)
-            records = [r for r in gathered if r is not None]
-        except Exception as e:  # noqa: BLE001  (the headline must survive a failed gather; the line then says so)
-            diag_err = f"rank records could not be gathered: {type(e).__name__}: {e}"
+    # ---- self-diagnosis, all of it OUTSIDE the timed region (round 6: the line must explain its own speed).  Every rank
+    # runs the passes that contain steps (their all-reduce keeps the ranks in lockstep); nothing here may cost the line.
+    diag = {"valu_before_ns": valu_before, "valu_after_ns": valu_ns, "clocks_reason": None if clock_fn else clock_src}
+    if not args.no_diagnose:
+        alg_launch = BYTES_PER_PX[args.format] * W * H * F / lpc
+        with torch.cuda.stream(stream), quiet_gc():
+            # (a) an event pair around every fused launch, six steps
+            diag["launches"] = instrumented_pass(be, step, barrier, 6, alg_launch)
+            # (b) the shader clock UNDER the kernel: two ordinary steps through the instance that stamps its clocks
+            try:
+                got_clock = []
+                for _ in range(2):
+                    step(develop=lambda arr: got_clock.append(be.measure_clock(arr, stream=stream.cuda_stream)))
+                barrier()
+                g = got_clock[-1]
+                diag["clock_under_kernel"] = {"GHz_median": round(g[0], 3), "GHz_min": round(g[1], 3), "GHz_max": round(g[2], 3),
+                                              "workgroup_busy_us_median": round(g[3], 1),
+                                              "note": "rd_batch_measure_clock: shader cycles / 100 MHz real-time ticks stamped by thread 0 of every "
+                                                      "workgroup of the last launch of an ordinary step, in a diagnostic instance of the kernel "
+                                                      "(no stamp executes in the timed region's instance)"}
+            except Exception as e:  # noqa: BLE001
+                diag["clock_under_kernel"] = {"error": f"{type(e).__name__}: {e}"}
+            # (c) board clocks / power / temperature while five more steps run
+            try:
+                if clock_fn:
+                    with ClockSampler(clock_fn) as smp:
+                        for _ in range(5):
+                            step()
+                        barrier()
+                    diag["clocks"] = dict(smp.summary(), source=clock_src, idle_before_the_run=clocks_idle,
+                                          note="sampled every ~4 ms on a host thread while five untimed steps of the same workload ran, "
+                                               "right after the timed region")
+                else:
+                    for _ in range(5):                     # the other ranks keep step with rank 0's sampled steps
+                        step()
+                    barrier()
+            except Exception as e:  # noqa: BLE001
+                diag["clocks"] = None
+                diag["clocks_reason"] = f"sampling failed: {type(e).__name__}: {e}"
+        # (d) the box probes again, after the region
+        if not args.no_box:
+            diag["box_after"] = measure_box(ra, dev_index)
+            if rank == 0:
+                diag["valu_after_probes_ns"] = measure_valu_ns(ra, dev_index)
+        # (e) rotating vs static descriptors, alternating, N = 1 only (the upload's cost on THIS box)
+        if world == 1 and len(arrays) > 1:
+            try:
+                ab = {"rotating": [], "static": []}
+                with torch.cuda.stream(stream), quiet_gc():
+                    for rep in range(3):
+                        for name in ("rotating", "static"):
+                            step(array=arrays[0] if name == "static" else None)      # settle: the static array is cached from here on
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(stream)
+                            for _ in range(4):
+                                step(array=arrays[0] if name == "static" else None)
+                            e1.record(stream)
+                            stream.synchronize()
+                            ab[name].append(e0.elapsed_time(e1) / 4.0)
+                    step()                                 # leave the ring as a regular step leaves it (the oracle check below reads it)
+                    stream.synchronize()
+                r_ms, s_ms = _median(ab["rotating"]), _median(ab["static"])
+                diag["descriptor_upload_ab"] = {"rotating_ms_per_step": round(r_ms, 4), "static_ms_per_step": round(s_ms, 4),
+                                                "rotating_all": [round(x, 4) for x in ab["rotating"]], "static_all": [round(x, 4) for x in ab["static"]],
+                                                "upload_cost_ms_per_step": round(r_ms - s_ms, 4),
+                                                "note": "3 x (4 steps rotating through the three frame arrays | 4 steps resubmitting ONE array, whose upload "
+                                                        "librawdev skips), alternating, HIP events, after the timed region"}
+            except Exception as e:  # noqa: BLE001
+                diag["descriptor_upload_ab"] = {"error": f"{type(e).__name__}: {e}"}
 
     if with_hist:                                          # sanity: the global histogram counts every pixel
         got = int(hist.sum().item())
@@ -1000,17 +1410,68 @@ def run_ranks(args):
         except Exception as e:  # noqa: BLE001  (oracle not built / not shipped: say so, do not claim)
             verified, verified_note = None, f"oracle check unavailable: {e}"
 
+    # (f) the memory pattern's own ceiling on this box, in these buffers: the same launches with the arithmetic removed
+    # (AFTER the check above: the surfaces receive raw samples)
+    if not args.no_diagnose and args.format == "f32":
+        try:
+            with torch.cuda.stream(stream), quiet_gc():
+                be.probe_pattern(arrays[0], stream=stream.cuda_stream)
+                stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for k in range(4):
+                    be.probe_pattern(arrays[(k + 1) % len(arrays)], stream=stream.cuda_stream)
+                e1.record(stream)
+                stream.synchronize()
+                p_ms = e0.elapsed_time(e1) / 4.0
+                be.set_launch_timing(3)
+                for k in range(3):
+                    be.probe_pattern(arrays[k % len(arrays)], stream=stream.cuda_stream)
+                stream.synchronize()
+                p_tl = launch_summary(be.launch_timeline(), BYTES_PER_PX["f32"] * W * H * F / lpc)
+                be.set_launch_timing(0)
+            diag["pattern"] = {"ms_per_step": round(p_ms, 4), "us_per_frame": round(p_ms * 1e3 / F, 2),
+                               "GBps": round(BYTES_PER_PX["f32"] * W * H * F / (p_ms * 1e-3) / 1e9, 1),
+                               "launch_us": (p_tl or {}).get("launch_us"), "GBps_median_launch": (p_tl or {}).get("GBps_median_launch"),
+                               "note": "rd_batch_probe_pattern: rd_develop_batch's own loads, LDS-DMA sweeps, tile tickets, LDS store stage and "
+                                       "non-temporal stores with the colour stack, gamma and histogram removed, over the SAME planes and the SAME "
+                                       "output ring, 4 steps back to back (HIP events); what this memory pattern costs on this box"}
+        except Exception as e:  # noqa: BLE001
+            diag["pattern"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                be.set_launch_timing(0)
+            except Exception:  # noqa: BLE001
+                pass
+
+    # every rank's own account of the region, gathered on rank 0 (N = 1: the one record)
+    mine = rank_record(rank, local_rank, dev_index, ident, elapsed_own, dev_ms, args.steps, F, W, H, lpc, box)
+    la = diag.get("launches") or {}
+    mine.update({"visibility": visibility, "devices_visible": ndev, "launch_us": la.get("launch_us"), "kernel_ms_per_step": la.get("kernel_ms_per_step"),
+                 "step_boundary_gap_us": la.get("step_boundary_gap_us"),
+                 "clock_under_kernel_GHz": (diag.get("clock_under_kernel") or {}).get("GHz_median"),
+                 "box_pattern_GBps": (diag.get("pattern") or {}).get("GBps"),
+                 "box_after_copy_GBps": (diag.get("box_after") or {}).get("copy"), "box_after_fill_GBps": (diag.get("box_after") or {}).get("fill")})
+    records, diag_err = [mine], None
+    world_seen = 1
+    if world > 1:
+        world_seen = dist.get_world_size()
+        try:
+            gathered = [None] * world_seen
+            dist.all_gather_object(gathered, mine)
+            records = [r for r in gathered if r is not None]
+        except Exception as e:  # noqa: BLE001  (the headline must survive a failed gather; the line then says so)
+            diag_err = f"rank records could not be gathered: {type(e).__name__}: {e}"
+
     # One rd_batch_develop call = `lpc` fused launches (the library packs up to 8 consecutive frames into one launch;
     # RD_BATCH_PERSISTENT=0 gives one launch per frame / row band).  Algorithmic bytes per launch = SURVEY 8(d)'s
     # per-pixel figure x the pixels one launch processes.
-    lpc = max(1, be.last_launch_count())
     unmeasured = ("; N > 1 on DISTINCT devices had never run before this line was produced on a multi-GPU node -- check "
                   "`distinct_devices` == n_gpus" if world > 1 else "")
     result = result_line(args, world, F, W, H, elapsed, dev_ms, lpc, len(ring), verified, verified_note,
                          "one process per GPU (torch.distributed, backend " + (backend if world > 1 else "none: single rank") + ")" + unmeasured,
                          "one frame array resubmitted every step (upload skipped)" if args.static_descriptors else
                          "steps rotate through three frame arrays (the slider stacks rotated by a third of the batch); librawdev caches "
-                         "the last two arrays it saw, so every step uploads its descriptors", box=box, valu_ns=valu_ns)
+                         "the last two arrays it saw, so every step uploads its descriptors", box=box, valu_ns=valu_ns, diag=diag)
     if rank == 0:
         # as-nccl: the duplicate-device rule applies to this run (nccl always; RAWDEV_DIAG_ASSUME_NCCL=1 lets the gloo
         # rehearsal on a one-GPU box prove that the rule fires)
@@ -1161,6 +1622,8 @@ def run_node(args):
     for _ in range(args.warmup):
         step()
     nb.synchronize()
+    if with_hist and not drain and args.warmup:
+        nb.histogram_fetch()                               # the warm-up's counts: fetch returns everything enqueued since the last fetch
     s0 = torch.cuda.ExternalStream(nb.stream(0), device=torch.device("cuda", devices[0]))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with quiet_gc():
@@ -1175,12 +1638,14 @@ def run_node(args):
         nb.synchronize()
         elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                         # HIP events on device 0's launch stream
+    hist_steps = 1
     if with_hist and not drain:
-        hist = nb.histogram_fetch()                        # the last step's global histogram (its read-back landed before the synchronise)
+        hist = nb.histogram_fetch()                        # every timed step's interval, summed (ABI 5; the read-backs landed before the synchronise)
+        hist_steps = args.steps
 
     if with_hist:
         got = int(hist.sum())
-        assert got == 3 * N * F * W * H, f"histogram sum {got} != {3 * N * F * W * H}"
+        assert got == 3 * N * F * W * H * hist_steps, f"histogram sum {got} != {3 * N * F * W * H * hist_steps}"
     verified, verified_note = None, "not checked"
     try:
         cfas, params, ring = per_dev[0]

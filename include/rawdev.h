@@ -42,8 +42,11 @@ extern "C" {
  * rd_debug_inject_fault.  RGB8 export (rd_batch_create, rd_exporter_create, rd_render) takes any even width from 128 up,
  * and every even width >= 128 runs the export kernel's whole-tile instances (it was W % 128 == 0).  rd_node_batch_* keeps
  * one worker thread per device for the life of the handle instead of starting N threads per call; new entry points
- * rd_node_batch_histogram_enqueue / _fetch (the global histogram without draining the devices). */
-#define RD_ABI_VERSION 4
+ * rd_node_batch_histogram_enqueue / _fetch (the global histogram without draining the devices).
+ * 5: no signature changed.  rd_node_batch_histogram_fetch returns the SUM of every interval enqueued since the last fetch
+ * (ABI 4 returned the last one and dropped the others); new measurement aids rd_batch_set_launch_timing,
+ * rd_batch_launch_timeline, rd_batch_probe_pattern, rd_batch_measure_clock. */
+#define RD_ABI_VERSION 5
 
 typedef enum rd_status {
     RD_OK = 0,
@@ -246,6 +249,30 @@ int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t format, uin
                            size_t counts_cap);
 /* Number of fused kernel launches the last rd_batch_develop call on this context enqueued (measurement aid). */
 uint32_t rd_batch_last_launch_count(const rd_batch *b);
+/* Measurement aids (bench.py's launch_us_by_position / kernel_ms_per_step / frac_of_box_pattern; a host never needs them).
+ * rd_batch_set_launch_timing: keep a HIP event pair around every fused launch of the last `keep_calls` develop / probe
+ * calls of this context (0 = off, the default; at most 64).  The pairs put two barrier packets between neighbouring
+ * launches: a timed call is for looking at, not for quoting.
+ * rd_batch_launch_timeline: after the caller has synchronised the stream -- the kept launches, oldest first: start and end
+ * of each in microseconds since the first kept launch's start, and the call each belongs to (0 = the oldest kept call).
+ * At most `cap` entries are written; *n_launches = how many are kept.  Any of the three arrays may be NULL.
+ * rd_batch_probe_pattern: the launches rd_batch_develop would enqueue for these frames with the kernel's ARITHMETIC
+ * REMOVED -- every load, sweep, tile ticket, LDS stage and store of the RGBA-f32 export kernel, on the caller's own planes
+ * and surfaces, which receive the raw samples as floats (NOT a develop; the histogram is not touched).  Timed, it is what
+ * the kernel's memory pattern alone costs on this box in these buffers.  RGBA-f32 contexts with multi-frame launches only,
+ * frames the read-burst instance takes (width >= 128, 16-byte aligned planes); RD_ERR_UNSUPPORTED otherwise. */
+int rd_batch_set_launch_timing(rd_batch *b, uint32_t keep_calls);
+int rd_batch_launch_timeline(rd_batch *b, float *start_us, float *end_us, uint32_t *call_index, size_t cap,
+                             uint32_t *n_launches);
+int rd_batch_probe_pattern(rd_batch *b, const rd_frame *frames, size_t n_frames, void *stream);
+/* rd_batch_measure_clock: the shader clock the part holds UNDER the export kernel (it is power-managed: a pure-VALU loop,
+ * a copy and this kernel each get a different one, and devices differ).  One ordinary develop of these frames -- surfaces
+ * written, histogram counted -- through the one kernel instance in which thread 0 of every workgroup stamps the cycle counter
+ * and the 100 MHz real-time counter into a buffer nothing else reads; synchronises; reports cycles / ticks x 100 MHz over the
+ * workgroups of the LAST launch (median / min / max) and the median workgroup's busy time.  RGBA-f32 contexts with
+ * histogram, strict arithmetic and multi-frame launches only (the headline's instance); any output may be NULL. */
+int rd_batch_measure_clock(rd_batch *b, const rd_frame *frames, size_t n_frames, void *stream, double *ghz_median,
+                           double *ghz_min, double *ghz_max, double *workgroup_us_median);
 /* Reduce the accumulated histogram into `hist_dev` (768 x u64 on the device: R[256] G[256] B[256])
  * and reset the accumulator.  Enqueued on `stream`; the multi-GPU sum is the caller's all-reduce. */
 int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream);
@@ -277,7 +304,9 @@ int rd_node_batch_histogram(rd_node_batch *nb, uint64_t hist[768]);
 /* The same in two halves, for a host that develops call after call and must not drain its devices in between (round 5):
  * _enqueue puts the per-device fold, the all-reduce and the read-back (into a page-locked buffer the handle owns) on the
  * devices' streams and returns at once; _fetch waits for those read-backs only -- not for develop calls enqueued after them --
- * and hands out the sum.  One result may be outstanding: only the LAST enqueue's result is what fetch returns. */
+ * and hands out the sum.  Intervals add up (ABI 5): _fetch returns everything developed since the previous _fetch (or
+ * rd_node_batch_histogram), however many _enqueue calls lie between -- no interval is discarded -- and fails with
+ * RD_ERR_INVALID_ARG when nothing has been enqueued since then. */
 int rd_node_batch_histogram_enqueue(rd_node_batch *nb);
 int rd_node_batch_histogram_fetch(rd_node_batch *nb, uint64_t hist[768]);
 int rd_node_batch_synchronize(rd_node_batch *nb);

@@ -11,7 +11,7 @@ from .build import LIB_PATH
 RD_OK = 0
 RD_ERR_INVALID_ARG, RD_ERR_NO_DEVICE, RD_ERR_HIP, RD_ERR_OOM, RD_ERR_UNSUPPORTED, RD_ERR_INTERNAL = -1, -2, -3, -4, -5, -6   # rd_status
 FAULT_BAD_ALLOC, FAULT_THREAD_START, FAULT_RUNTIME, FAULT_FOREIGN = 1, 2, 3, 4                                            # rd_fault_kind
-ABI_VERSION = 4          # include/rawdev.h RD_ABI_VERSION
+ABI_VERSION = 5          # include/rawdev.h RD_ABI_VERSION
 FMT_RGBA_F32, FMT_RGBA_F16, FMT_RGBA_U8, FMT_RGB_U8 = 0, 1, 2, 3
 MATH_STRICT, MATH_CONTRACTED = 0, 1
 MATRIX_REFERENCE, MATRIX_ROW_MAJOR = 0, 1
@@ -82,6 +82,10 @@ PROTOTYPES = {
     "rd_batch_develop": (_I, [_VP, C.POINTER(RdFrame), _SZ, _U32, _VP]),
     "rd_batch_plan_launches": (_I, [_U32, _U32, _U32, _U32, C.POINTER(RdFrame), _SZ, _U32, C.POINTER(_U32), _SZ]),
     "rd_batch_last_launch_count": (_U32, [_VP]),
+    "rd_batch_set_launch_timing": (_I, [_VP, _U32]),
+    "rd_batch_launch_timeline": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_U32), _SZ, C.POINTER(_U32)]),
+    "rd_batch_probe_pattern": (_I, [_VP, C.POINTER(RdFrame), _SZ, _VP]),
+    "rd_batch_measure_clock": (_I, [_VP, C.POINTER(RdFrame), _SZ, _VP] + [C.POINTER(C.c_double)] * 4),
     "rd_batch_histogram": (_I, [_VP, _VP, _VP]),
     "rd_node_batch_create": (_I, [C.POINTER(_I), _U32, _U32, _U32, _U32, _U32, C.POINTER(_VP)]),
     "rd_node_batch_destroy": (None, [_VP]),

@@ -69,7 +69,8 @@ class NodeBatch:
         check(_lib.lib().rd_node_batch_histogram_enqueue(self._h))
 
     def histogram_fetch(self):
-        """The last histogram_enqueue()'s (3, 256) uint64 result; waits for its read-back only."""
+        """(3, 256) uint64 counts of everything developed since the last fetch (every histogram_enqueue() in between
+        adds its interval); waits for the last read-back only."""
         import numpy as np
         out = np.zeros(768, np.uint64)
         check(_lib.lib().rd_node_batch_histogram_fetch(self._h, out.ctypes.data_as(C.c_void_p)))
@@ -141,6 +142,35 @@ class BatchExporter:
     def last_launch_count(self) -> int:
         """Fused kernel launches the last develop() enqueued (multi-frame launches cover up to 8 frames each)."""
         return int(_lib.lib().rd_batch_last_launch_count(self._h))
+
+    def set_launch_timing(self, keep_calls: int) -> None:
+        """Measurement aid: keep a HIP event pair around every fused launch of the last `keep_calls` develop() /
+        probe_pattern() calls (0 = off).  The pairs sit between the launches: look at a timed call, quote an untimed one."""
+        check(_lib.lib().rd_batch_set_launch_timing(self._h, int(keep_calls)))
+
+    def launch_timeline(self):
+        """After the stream has been synchronised: [(call, start_us, end_us), ...] of the kept launches, oldest first
+        (times since the first kept launch's start; call 0 = the oldest kept call)."""
+        n = C.c_uint32(0)
+        check(_lib.lib().rd_batch_launch_timeline(self._h, None, None, None, 0, C.byref(n)))
+        if not n.value:
+            return []
+        st, en, ca = (C.c_float * n.value)(), (C.c_float * n.value)(), (C.c_uint32 * n.value)()
+        check(_lib.lib().rd_batch_launch_timeline(self._h, st, en, ca, n.value, C.byref(n)))
+        return [(int(ca[i]), float(st[i]), float(en[i])) for i in range(n.value)]
+
+    def probe_pattern(self, frames, stream: int = 0) -> None:
+        """Measurement aid: develop()'s launches for these frames with the arithmetic removed (rd_batch_probe_pattern) --
+        the surfaces receive the raw samples as floats.  RGBA-f32 contexts only."""
+        check(_lib.lib().rd_batch_probe_pattern(self._h, frames, len(frames), C.c_void_p(stream) if stream else None))
+
+    def measure_clock(self, frames, stream: int = 0):
+        """Measurement aid (rd_batch_measure_clock): one ordinary develop of `frames` through the kernel instance that stamps
+        its clocks, synchronised -> (GHz median, min, max over the last launch's workgroups, median workgroup busy us)."""
+        v = [C.c_double(0.0) for _ in range(4)]
+        check(_lib.lib().rd_batch_measure_clock(self._h, frames, len(frames), C.c_void_p(stream) if stream else None,
+                                                *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def histogram(self, hist_dev: int, stream: int = 0) -> None:
         """Fold the accumulated counts into a device u64[768] and reset the accumulator."""

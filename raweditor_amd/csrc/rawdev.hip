@@ -388,21 +388,27 @@ struct rd_scratch {
             idx = (int)ents.size() - 1;
         }
         if (idx < 0) {                                           // recycle: least recently used among the finished ones
-            // (an entry whose last use carries no marker -- it was used while the table still had room, see used() -- may be
-            //  in flight for all we know: one device synchronise settles them all; the 17th stream of a pipeline is rare)
-            bool unknown = false;
-            for (const entry &e : ents) unknown = unknown || !e.recorded;
-            const bool drained = unknown && hipDeviceSynchronize() == hipSuccess;
-            if (unknown && !drained) for (entry &e : ents) e.dirty = true;
+            // An entry whose last use carries no marker -- it was used while the table still had room, see used() -- is asked
+            // through ITS OWN stream (hipStreamQuery: finished / not ready / the stream no longer exists, whose work is then
+            // over too).  Nothing here synchronises the device: this runs inside rd_render_device, an asynchronous enqueue that
+            // other streams of the device must not stall behind and that may sit next to a stream capture.
+            auto finished = [](entry &e) -> bool {
+                if (e.recorded) return hipEventQuery(e.done) == hipSuccess;
+                const hipError_t q = hipStreamQuery(e.stream);
+                if (q != hipSuccess) (void)hipGetLastError();
+                return q != hipErrorNotReady;                    // success, or a stream that has been destroyed
+            };
             int lru_done = -1, lru_any = 0;
             for (size_t i = 0; i < ents.size(); ++i) {
                 if (ents[i].stamp < ents[(size_t)lru_any].stamp) lru_any = (int)i;
-                const bool done = ents[i].recorded ? hipEventQuery(ents[i].done) == hipSuccess : drained;
-                if (done && (lru_done < 0 || ents[i].stamp < ents[(size_t)lru_done].stamp))
-                    lru_done = (int)i;
+                if (finished(ents[i]) && (lru_done < 0 || ents[i].stamp < ents[(size_t)lru_done].stamp)) lru_done = (int)i;
             }
             idx = lru_done >= 0 ? lru_done : lru_any;
-            if (lru_done < 0 && (!ents[(size_t)idx].recorded || hipEventSynchronize(ents[(size_t)idx].done) != hipSuccess)) ents[(size_t)idx].dirty = true;
+            if (lru_done < 0) {                                  // every entry busy: wait for the least recently used one alone
+                entry &v = ents[(size_t)idx];
+                const hipError_t w = v.recorded ? hipEventSynchronize(v.done) : hipStreamSynchronize(v.stream);
+                if (w != hipSuccess) { (void)hipGetLastError(); v.dirty = true; }
+            }
             ents[(size_t)idx].stream = s;
         }
         entry &e = ents[(size_t)idx];
@@ -516,10 +522,24 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     if (!record) (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
 }
 
+// Does a multi-frame launch of W x H frames take the read-burst instance (f32 surface)?  The pattern probe
+// (rd_batch_probe_pattern) is built for that instance only.
+static bool rd_burst_launchable(uint32_t W, uint32_t H, bool aligned16)
+{
+    return aligned16 && W >= 128u && (W % 2u) == 0 && (uint64_t)(H / 2u + 1u) * W >= (1u << 19);
+}
+static bool rd_probe_launchable(uint32_t W, uint32_t H, bool aligned16)
+{
+    static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;
+    return rd_burst_launchable(W, H, aligned16) && burst_env != 0;
+}
+
 // Multi-frame launch (rd_develop_batch): descs_dev[0 .. nframes-1] are whole frames of W x H.
+// stamps != nullptr: the diagnostic instance that stamps its clocks per workgroup (rd_kernels.h, STAMP; f32 + histogram +
+// strict arithmetic + read burst only: what rd_batch_measure_clock checks before it asks for it).
 template <int FMT, bool HIST, int MATH>
 static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, uint32_t W, uint32_t H, uint32_t blocks,
-                              bool burst_ok, unsigned long long *slab64, uint32_t *tq, hipStream_t s)
+                              bool burst_ok, unsigned long long *slab64, uint32_t *tq, hipStream_t s, uint32_t *stamps = nullptr)
 {
     const uint32_t tpu = ((W >> 1) + 63u) / 64u;
     const uint32_t tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;
@@ -532,12 +552,22 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
     const uint32_t ndyn = ntiles > nwaves ? ntiles - nwaves : 0u;
     const uint32_t tq_tmax = tq_k ? (ndyn + tq_k - 1u) / tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;
-    const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && W >= 128u && (uint64_t)(H / 2u + 1u) * W >= (1u << 19) &&
-                       (burst_env < 0 || burst_env != 0);
+    const bool burst = FMT == RD_FMT_RGBA_F32 && rd_burst_launchable(W, H, burst_ok) && (burst_env < 0 || burst_env != 0);
     const int tiles = rd_tiles_mode(W);
 #define RD_LAUNCH_BATCH(TILES, BURST)                                                                                        \
     hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, TILES, MATH, BURST>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes, \
-                       W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64)
+                       W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64, (uint32_t *)nullptr)
+    if constexpr (FMT == RD_FMT_RGBA_F32 && HIST && MATH == RD_MATH_STRICT) {
+        if (stamps && burst) {
+#define RD_LAUNCH_STAMPED(TILES)                                                                                             \
+    hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, TILES, MATH, true, true>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev,    \
+                       nframes, W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64, stamps)
+            if (tiles == RD_TILES_WHOLE) RD_LAUNCH_STAMPED(RD_TILES_WHOLE);
+            else RD_LAUNCH_STAMPED(RD_TILES_OVERLAP);
+#undef RD_LAUNCH_STAMPED
+            return;
+        }
+    }
     if constexpr (FMT == RD_FMT_RGBA_F32) {
         if (burst) {
             if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, true);
@@ -545,6 +575,8 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
             return;
         }
     }
+    if constexpr (MATH == RD_MATH_PROBE) return;                 // (the probe has burst instances only: rd_probe_launchable)
+    else
     if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
     else if (tiles == RD_TILES_OVERLAP) RD_LAUNCH_BATCH(RD_TILES_OVERLAP, false);
     else RD_LAUNCH_BATCH(RD_TILES_MASKED, false);

@@ -37,6 +37,48 @@ struct rd_batch {
     } db[2];
     int db_last = 1;
     uint32_t last_launches = 0;                // fused launches enqueued by the last rd_batch_develop call
+    // Launch timing (measurement aid, rd_batch_set_launch_timing): a HIP event pair around every fused launch of the last
+    // `timing_keep` develop calls, oldest first.  Off (0) by default: the pairs put two barrier packets between launches.
+    struct timed_launch { hipEvent_t start = nullptr, end = nullptr; uint32_t call = 0; };
+    uint32_t timing_keep = 0, timing_call = 0;
+    std::vector<timed_launch> timeline;
+    std::vector<hipEvent_t> ev_free;
+};
+
+// One timing event: a recycled one, or a new one (nullptr when the runtime refuses).
+static hipEvent_t rd_batch_timing_event(rd_batch *b)
+{
+    if (!b->ev_free.empty()) { hipEvent_t e = b->ev_free.back(); b->ev_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+
+// A timed develop call starts: forget the launches of calls that fell out of the window (their events are reused).
+static void rd_batch_timing_begin(rd_batch *b)
+{
+    if (!b->timing_keep) return;
+    b->timing_call += 1u;
+    size_t drop = 0;
+    while (drop < b->timeline.size() && b->timeline[drop].call + b->timing_keep <= b->timing_call) ++drop;
+    for (size_t i = 0; i < drop; ++i) { b->ev_free.push_back(b->timeline[i].start); b->ev_free.push_back(b->timeline[i].end); }
+    b->timeline.erase(b->timeline.begin(), b->timeline.begin() + (ptrdiff_t)drop);
+}
+
+struct rd_batch_timed {                        // RAII around ONE launch on stream s: start event now, end event on scope exit
+    rd_batch *b; hipStream_t s; rd_batch::timed_launch tl; bool on = false;
+    rd_batch_timed(rd_batch *bb, hipStream_t ss) : b(bb), s(ss)
+    {
+        if (!b->timing_keep) return;
+        tl.start = rd_batch_timing_event(b); tl.end = rd_batch_timing_event(b); tl.call = b->timing_call;
+        on = tl.start && tl.end && hipEventRecord(tl.start, s) == hipSuccess;
+        if (!on) { if (tl.start) b->ev_free.push_back(tl.start); if (tl.end) b->ev_free.push_back(tl.end); }
+    }
+    ~rd_batch_timed()
+    {
+        if (!on) return;
+        (void)hipEventRecord(tl.end, s);
+        b->timeline.push_back(tl);             // capacity reserved by rd_batch_set_launch_timing for 64 launches per call; beyond
+    }                                          // that a failed growth is caught at the C boundary (the events leak until destroy)
 };
 
 extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
@@ -113,6 +155,8 @@ extern "C" void rd_batch_destroy(rd_batch *b) try
             if (d.done) (void)hipEventDestroy(d.done);
             if (d.uploaded) (void)hipEventDestroy(d.uploaded);
         }
+        for (auto &t : b->timeline) { if (t.start) (void)hipEventDestroy(t.start); if (t.end) (void)hipEventDestroy(t.end); }
+        for (hipEvent_t e : b->ev_free) if (e) (void)hipEventDestroy(e);
         if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
         if (b->ev_join) (void)hipEventDestroy(b->ev_join);
         if (b->aux) (void)hipStreamDestroy(b->aux);
@@ -190,7 +234,8 @@ RD_CATCH_INT(rd_batch_plan_launches)
 // are stored inside one launch is not defined), never more pixels than a u32 histogram bin can count, and never more
 // tiles than the 32-bit tile index.  Row bands need no launches of their own here: the ticket front sweeps a frame in
 // row order, so a "band" is a range of tickets.
-static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n, hipStream_t s)
+static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n, hipStream_t s, bool probe = false,
+                                  uint32_t *stamps = nullptr)
 {
     if (!n) return RD_OK;
     const size_t bpp = rd_format_bytes_per_pixel(b->fmt);
@@ -244,17 +289,26 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     const rd_frame_desc *descs = b->db[j].dev;
 
     const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->hist, b->max_frames);
+    if ((probe || stamps) && !rd_probe_launchable(b->w, b->h, aligned16))
+        return rd_fail(RD_ERR_UNSUPPORTED, "the diagnostic instances exist for the read-burst kernel only: frames at least 128 pixels wide, "
+                                           "even width, 16-byte aligned CFA planes, at least 1 MB of CFA rows");
     const rd_scratch::lease l = b->scratch.get(s, false);
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     uint32_t *tq = l.tq;
     int rc = RD_OK;
     b->last_launches = 0;
+    rd_batch_timing_begin(b);
     (void)hipGetLastError();                     // see rd_enqueue_render
     for (size_t i0 = 0; i0 < n && rc == RD_OK;) {
         const size_t c = rd_next_launch_size(frames, n, i0, surf_bytes, kmax);
-        RD_DISPATCH(rd_launch_batch_t, b->fmt, b->hist, b->math_mode, descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16,
-                    b->slab64, tq, s);
-        hipError_t e = hipGetLastError();
+        hipError_t e;
+        {
+            rd_batch_timed timed(b, s);
+            if (probe) rd_launch_batch_t<RD_FMT_RGBA_F32, false, RD_MATH_PROBE>(descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16, b->slab64, tq, s);
+            else RD_DISPATCH(rd_launch_batch_t, b->fmt, b->hist, b->math_mode, descs + i0, (uint32_t)c, b->w, b->h, b->blocks, aligned16,
+                             b->slab64, tq, s, stamps);
+            e = hipGetLastError();
+        }
         if (e != hipSuccess) rc = rd_fail(RD_ERR_HIP, "multi-frame launch failed: %s", hipGetErrorString(e));
         else b->last_launches += 1;
         i0 += c;
@@ -284,6 +338,7 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
     int rc = RD_OK;
     size_t launch = 0;
     b->last_launches = 0;
+    rd_batch_timing_begin(b);
     rd_scratch::lease ls[2] = { b->scratch.get(lanes[0], false), rd_scratch::lease{} };
     if (fork) ls[1] = b->scratch.get(lanes[1], false);
     if (ls[0].idx < 0 || (fork && ls[1].idx < 0)) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
@@ -300,6 +355,7 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
             const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
             const size_t lane = fork ? (launch & 1u) : 0u;
             unsigned long long *slab = b->slab64 ? b->slab64 + lane * (size_t)b->blocks * 768u : nullptr;
+            rd_batch_timed timed(b, lanes[lane]);
             rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0, u1,
                                    b->hist, b->math_mode, nullptr, slab, b->blocks, ls[lane].tq, lanes[lane], nullptr);
             if (rc == RD_OK) b->last_launches += 1;
@@ -316,6 +372,108 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
 RD_CATCH_INT(rd_batch_develop)
 
 extern "C" uint32_t rd_batch_last_launch_count(const rd_batch *b) try { RD_ENTRY(rd_batch_last_launch_count); return b ? b->last_launches : 0u; } RD_CATCH_VAL(rd_batch_last_launch_count, 0)
+
+// Measurement aid: the launches rd_batch_develop would enqueue for these frames, with the kernel's arithmetic removed
+// (rd_kernels.h, RD_MATH_PROBE): every load, sweep, ticket, LDS stage and store of the f32 export kernel on the caller's
+// own planes and surfaces, which receive the raw samples as floats -- NOT a develop.  What the memory pattern alone costs
+// on this box, in these buffers: the honest ceiling of rd_develop_batch here (bench.py: roofline.box_pattern_GBps).
+extern "C" int rd_batch_probe_pattern(rd_batch *b, const rd_frame *frames, size_t n, void *stream) try
+{
+    RD_ENTRY(rd_batch_probe_pattern);
+    if (!b || (!frames && n)) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (b->fmt != RD_FMT_RGBA_F32 || !b->persistent)
+        return rd_fail(RD_ERR_UNSUPPORTED, "the pattern probe exists for the RGBA-f32 surface with multi-frame launches only");
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    return rd_batch_develop_multi(b, frames, n, (hipStream_t)stream, true);
+}
+RD_CATCH_INT(rd_batch_probe_pattern)
+
+// Measurement aid: the clock the part holds UNDER the export kernel.  One ordinary rd_batch_develop of these frames (the
+// surfaces are developed, the histogram counts them) through the one instance of the kernel that stamps the shader-cycle
+// counter and the 100 MHz real-time counter per workgroup, then a synchronise: cycles / ticks x 100 MHz of the LAST launch,
+// over its workgroups.  RGBA-f32 + histogram + strict arithmetic + multi-frame launches only (the headline's instance).
+extern "C" int rd_batch_measure_clock(rd_batch *b, const rd_frame *frames, size_t n, void *stream, double *ghz_median,
+                                      double *ghz_min, double *ghz_max, double *workgroup_us_median) try
+{
+    RD_ENTRY(rd_batch_measure_clock);
+    if (!b || !frames || !n) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    if (b->fmt != RD_FMT_RGBA_F32 || !b->hist || !b->persistent || b->math_mode != RD_MATH_STRICT)
+        return rd_fail(RD_ERR_UNSUPPORTED, "the stamped instance exists for the RGBA-f32 surface with histogram, strict arithmetic and "
+                                           "multi-frame launches only");
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    struct res { uint32_t *dev = nullptr; ~res() { if (dev) (void)hipFree(dev); } } r;
+    const size_t bytes = (size_t)b->blocks * 2u * sizeof(uint32_t);
+    RD_HIP(hipMalloc((void **)&r.dev, bytes));
+    RD_HIP(hipMemsetAsync(r.dev, 0, bytes, (hipStream_t)stream));
+    int rc = rd_batch_develop_multi(b, frames, n, (hipStream_t)stream, false, r.dev);
+    std::vector<uint32_t> st((size_t)b->blocks * 2u);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);     // before r.dev goes, whatever rc says
+    if (rc) return rc;
+    RD_HIP(e);
+    RD_HIP(hipMemcpy(st.data(), r.dev, bytes, hipMemcpyDeviceToHost));
+    std::vector<double> ghz, us;
+    for (uint32_t k = 0; k < b->blocks; ++k)
+        if (st[2u * k] && st[2u * k + 1u]) { ghz.push_back((double)st[2u * k] / (double)st[2u * k + 1u] * 0.1); us.push_back((double)st[2u * k + 1u] * 0.01); }
+    if (ghz.empty()) return rd_fail(RD_ERR_HIP, "no workgroup left a clock stamp");
+    std::sort(ghz.begin(), ghz.end());
+    std::sort(us.begin(), us.end());
+    if (ghz_median) *ghz_median = ghz[ghz.size() / 2];
+    if (ghz_min) *ghz_min = ghz.front();
+    if (ghz_max) *ghz_max = ghz.back();
+    if (workgroup_us_median) *workgroup_us_median = us[us.size() / 2];
+    return RD_OK;
+}
+RD_CATCH_INT(rd_batch_measure_clock)
+
+// Measurement aid: keep a HIP event pair around every fused launch of the last `keep_calls` rd_batch_develop /
+// rd_batch_probe_pattern calls (0 = off, the default; at most 64 calls).
+extern "C" int rd_batch_set_launch_timing(rd_batch *b, uint32_t keep_calls) try
+{
+    RD_ENTRY(rd_batch_set_launch_timing);
+    if (!b) return rd_fail(RD_ERR_INVALID_ARG, "NULL batch");
+    if (keep_calls > 64u) return rd_fail(RD_ERR_INVALID_ARG, "at most 64 calls can be kept (got %u)", keep_calls);
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    b->timeline.reserve((size_t)keep_calls * 64u + 64u);
+    b->ev_free.reserve((size_t)keep_calls * 128u + 128u);
+    for (auto &t : b->timeline) { b->ev_free.push_back(t.start); b->ev_free.push_back(t.end); }
+    b->timeline.clear();
+    b->timing_keep = keep_calls;
+    b->timing_call = 0;
+    return RD_OK;
+}
+RD_CATCH_INT(rd_batch_set_launch_timing)
+
+// The kept launches, oldest first, after the caller has synchronised the stream(s): start and end of each launch in
+// microseconds since the FIRST kept launch's start event, and the call it belongs to (0 = the oldest kept call).  Writes at
+// most `cap` entries, *n_out = how many are kept.  A launch's duration is end - start; the idle time before it is its start
+// minus its predecessor's end (across a call boundary that gap holds the histogram fold and the descriptor upload).
+extern "C" int rd_batch_launch_timeline(rd_batch *b, float *start_us, float *end_us, uint32_t *call_index, size_t cap,
+                                        uint32_t *n_out) try
+{
+    RD_ENTRY(rd_batch_launch_timeline);
+    if (!b || !n_out) return rd_fail(RD_ERR_INVALID_ARG, "NULL argument");
+    *n_out = (uint32_t)b->timeline.size();
+    if (b->timeline.empty()) return RD_OK;
+    rd_devguard g(b->device);
+    if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
+    const hipEvent_t origin = b->timeline.front().start;
+    const uint32_t call0 = b->timeline.front().call;
+    for (size_t i = 0; i < b->timeline.size() && i < cap; ++i) {
+        float t0 = 0.0f, t1 = 0.0f;
+        hipError_t e = hipEventElapsedTime(&t0, origin, b->timeline[i].start);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t1, origin, b->timeline[i].end);
+        if (e != hipSuccess)
+            return rd_fail(RD_ERR_HIP, "launch %zu of the timeline: %s (synchronise the stream before reading it)", i, hipGetErrorString(e));
+        if (start_us) start_us[i] = t0 * 1e3f;
+        if (end_us) end_us[i] = t1 * 1e3f;
+        if (call_index) call_index[i] = b->timeline[i].call - call0;
+    }
+    return RD_OK;
+}
+RD_CATCH_INT(rd_batch_launch_timeline)
 
 extern "C" int rd_batch_histogram(rd_batch *b, uint64_t *hist_dev, void *stream) try
 {
@@ -406,7 +564,8 @@ struct rd_node_batch {
     std::vector<int> devices;
     std::vector<rd_batch *> batches;
     std::vector<hipStream_t> streams;
-    std::vector<uint64_t *> hist_dev;          // 768 x u64 per device
+    std::vector<uint64_t *> hist_dev;          // 768 x u64 per device: the interval of the last enqueue (after an all-reduce: its global sum)
+    std::vector<uint64_t *> hist_acc;          // 768 x u64 per device: the intervals enqueued since the last fetch, summed
     uint64_t *hist_pin = nullptr;              // page-locked, n x 768: where rd_node_batch_histogram_enqueue's read-backs land
     std::vector<hipEvent_t> hist_ready;        // per device: its read-back has landed
     uint32_t hist_pending = 0;                 // devices whose read-back the next fetch waits for (0: nothing enqueued)
@@ -441,6 +600,7 @@ extern "C" void rd_node_batch_destroy(rd_node_batch *nb) try
         if (!any) continue;
         rd_devguard g(nb->devices[d]);
         if (nb->hist_dev[d]) (void)hipFree(nb->hist_dev[d]);
+        if (d < nb->hist_acc.size() && nb->hist_acc[d]) (void)hipFree(nb->hist_acc[d]);
         if (d < nb->hist_ready.size() && nb->hist_ready[d]) (void)hipEventDestroy(nb->hist_ready[d]);
         if (nb->streams[d]) (void)hipStreamDestroy(nb->streams[d]);
     }
@@ -477,6 +637,7 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
     nb->batches.assign(n_devices, nullptr);
     nb->streams.assign(n_devices, nullptr);
     nb->hist_dev.assign(n_devices, nullptr);
+    nb->hist_acc.assign(n_devices, nullptr);
     nb->hist_ready.assign(n_devices, nullptr);
     nb->comms.assign(n_devices, nullptr);
     nb->share.resize(n_devices);
@@ -487,8 +648,14 @@ extern "C" int rd_node_batch_create(const int *devices, uint32_t n_devices, uint
         rd_devguard g(devices[d]);
         hipError_t e = hipStreamCreateWithFlags(&nb->streams[d], hipStreamNonBlocking);
         if (e == hipSuccess && nb->hist) e = hipMalloc((void **)&nb->hist_dev[d], 768 * sizeof(uint64_t));
+        if (e == hipSuccess && nb->hist) e = hipMalloc((void **)&nb->hist_acc[d], 768 * sizeof(uint64_t));
+        if (e == hipSuccess && nb->hist) e = hipMemset(nb->hist_acc[d], 0, 768 * sizeof(uint64_t));
         if (e == hipSuccess && nb->hist) e = hipEventCreateWithFlags(&nb->hist_ready[d], hipEventDisableTiming);
-        if (e == hipSuccess && nb->hist && d == 0) e = hipHostMalloc((void **)&nb->hist_pin, (size_t)n_devices * 768 * sizeof(uint64_t), hipHostMallocPortable);
+        // page-locked, visible to every device of the node, host-coherent: the read-back kernels store into it and the
+        // host reads it after their event -- the three properties are REQUESTED, not left to the HIP_HOST_COHERENT default
+        if (e == hipSuccess && nb->hist && d == 0)
+            e = hipHostMalloc((void **)&nb->hist_pin, (size_t)n_devices * 768 * sizeof(uint64_t),
+                              hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
         if (e != hipSuccess) rc = rd_fail(e == hipErrorOutOfMemory ? RD_ERR_OOM : RD_ERR_HIP, "device %d: %s", devices[d], hipGetErrorString(e));
     }
     if (rc == RD_OK && nb->hist) {
@@ -619,12 +786,14 @@ RD_CATCH_INT(rd_node_batch_synchronize)
 // The global histogram in two halves, so that a host which runs step after step need not drain its devices for it (the
 // one-process-per-GPU host never does: its fold and all-reduce are stream-ordered):
 //   enqueue: per-device fold of the slabs into 768 x u64 on each device's stream (behind the launches enqueued there), the
-//            RCCL all-reduce in place (one group), and the read-back into the handle's page-locked buffer -- of device 0
-//            after an all-reduce (every device then holds the sum), of every device for the host fold.  Nothing is waited for.
+//            RCCL all-reduce in place (one group), then ONE small kernel per read-back device that adds the interval to the
+//            device's running sum (hist_acc: everything enqueued since the last fetch) and stores that sum into the handle's
+//            page-locked buffer -- device 0 after an all-reduce (every device then holds the interval's global sum), every
+//            device for the host fold.  Nothing is waited for.
 //   fetch:   waits for those read-backs only (an event per device, not the streams: develop calls already enqueued behind
-//            them keep running) and hands out the sum.  One result may be outstanding: a second enqueue before the fetch
-//            overwrites the first (its counts are NOT lost -- they were folded into the device buffers and read back -- but
-//            only the last enqueue's result is what fetch returns).
+//            them keep running), hands out the sum of EVERY interval enqueued since the last fetch, and enqueues the reset
+//            of the running sums.  So a host may enqueue after every develop call and fetch once (bench.py --host node):
+//            no interval is lost, and "everything developed since the last fetch" holds for any mix of the two forms.
 static int rd_node_histogram_enqueue(rd_node_batch *nb)
 {
     for (uint32_t d = 0; d < nb->n; ++d) {
@@ -643,25 +812,23 @@ static int rd_node_histogram_enqueue(rd_node_batch *nb)
         if (r != 0) return rd_fail(RD_ERR_HIP, "ncclAllReduce: %s", api.GetErrorString(r));
     }
     const uint32_t take = nb->reduce == RD_NODE_REDUCE_HOST ? nb->n : 1u;      // after an all-reduce every device holds the sum
-    // The read-back is a 768-thread KERNEL that stores into the page-locked buffer (host-coherent, mapped into every device),
-    // not a hipMemcpyAsync: a copy-engine transfer between two kernels of one stream is ordered through signals on both
-    // sides and leaves the compute queue idle meanwhile, once per step (RD_NODE_HIST_DMA=1 keeps that form for A/B).
-    static const bool dma = rd_env_u32("RD_NODE_HIST_DMA", 0) != 0;
+    // The read-back is a 768-thread KERNEL that stores into the page-locked buffer, not a hipMemcpyAsync: a copy-engine
+    // transfer between two kernels of one stream is ordered through signals on both sides and leaves the compute queue idle
+    // meanwhile, once per step.  Its visibility to the host rests on the buffer being host-coherent (requested at create)
+    // and on the system-scope release of the kernel's end, which the event waits for.
+    // hist_pending stays 0 until EVERY read-back and its event are enqueued: a failure half way leaves "nothing enqueued"
+    // for fetch to report, never the sum of the first k devices.
     nb->hist_pending = 0;
     for (uint32_t d = 0; d < take; ++d) {
         rd_devguard g(nb->devices[d]);
         if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
         uint64_t *dst = nb->hist_pin + (size_t)d * 768u;
-        if (dma) {
-            RD_HIP(hipMemcpyAsync(dst, nb->hist_dev[d], 768 * sizeof(uint64_t), hipMemcpyDeviceToHost, nb->streams[d]));
-        } else {
-            hipLaunchKernelGGL(rd_copy_hist64, dim3(1), dim3(768), 0, nb->streams[d], (const unsigned long long *)nb->hist_dev[d],
-                               (unsigned long long *)dst);
-            RD_HIP(hipGetLastError());
-        }
+        hipLaunchKernelGGL(rd_acc_hist64, dim3(1), dim3(768), 0, nb->streams[d], (const unsigned long long *)nb->hist_dev[d],
+                           (unsigned long long *)nb->hist_acc[d], (unsigned long long *)dst);
+        RD_HIP(hipGetLastError());
         RD_HIP(hipEventRecord(nb->hist_ready[d], nb->streams[d]));
-        nb->hist_pending = d + 1u;
     }
+    nb->hist_pending = take;
     return RD_OK;
 }
 
@@ -676,7 +843,13 @@ static int rd_node_histogram_fetch(rd_node_batch *nb, uint64_t hist[768])
         const uint64_t *part = nb->hist_pin + (size_t)d * 768u;
         for (int k = 0; k < 768; ++k) hist[k] += part[k];
     }
+    const uint32_t took = nb->hist_pending;
     nb->hist_pending = 0;
+    for (uint32_t d = 0; d < took; ++d) {                        // the running sums start again (stream-ordered behind the read-backs)
+        rd_devguard g(nb->devices[d]);
+        if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", nb->devices[d]);
+        RD_HIP(hipMemsetAsync(nb->hist_acc[d], 0, 768 * sizeof(uint64_t), nb->streams[d]));
+    }
     return RD_OK;
 }
 

@@ -173,11 +173,11 @@ static int rd_pipeline_new(int device, int64_t image_id, const uint16_t *cfa, bo
     if (!p) return rd_fail(RD_ERR_OOM, "host allocation failed");
     struct undo { void operator()(rd_pipeline *q) const { rd_pipeline_destroy(q); } };
     std::unique_ptr<rd_pipeline, undo> hold(p);                  // whatever throws below: the half-built pipeline is destroyed
+    p->device = device;                                          // first: the undo synchronises and frees on THIS device
+    p->cfg.n_cu = n_cu;
     RD_FAULT_POINT("pipeline.lanes");
     p->lanes.reserve(RD_LANES_MAX);
     p->lents.reserve(RD_LENT_MAX);
-    p->device = device;
-    p->cfg.n_cu = n_cu;
     p->cfg.wg_per_cu_plain = rd_env_u32("RD_WG_PER_CU", 2);
     p->info.width = w; p->info.height = h; p->info.image_id = image_id;
     rd_derived_dims(w, h, &p->info.preview_width, &p->info.preview_height, &p->info.histogram_width,

@@ -31,6 +31,13 @@
 #define RD_HK 8             // private histogram copies per bin: lane l adds into copy l % RD_HK
 #endif
 
+// Third value of the kernels' MATH parameter beside rd_math_mode's two (rawdev.h): NO arithmetic.  The export kernel's
+// f32 instance with every memory instruction, ticket, sweep and LDS stage of the real one and the colour stack, the gamma
+// and the histogram removed -- the surfaces receive the raw samples as floats.  Reachable only through
+// rd_batch_probe_pattern (a measurement aid: the memory pattern's own ceiling on this box, in these buffers); no render
+// entry point accepts it.
+#define RD_MATH_PROBE 2
+
 typedef float rd_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rd_u2 __attribute__((ext_vector_type(2)));
 typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
@@ -871,12 +878,17 @@ static_assert(sizeof(rd_frame_desc) == 192, "rd_frame_desc is three 64-byte line
 //                computed while the previous frame's last ones are still being stored.  A wave re-reads the
 //                uniforms (scalar loads, ~190 B) only when its compute stage changes frame: about once per
 //                (tiles per frame / resident waves) = 11 tiles at 24 MP.
-template <int FMT, bool HIST, int TILES, int MATH, bool BURST, bool MULTI>
+// STAMP = true (one diagnostic instance, rd_batch_measure_clock; in every other instance no stamp executes): thread 0 of each
+//                workgroup reads the shader-cycle counter and the 100 MHz real-time counter after the prologue and at the end
+//                and stores the two differences into stamps[2 * blockIdx.x ..] -- a buffer nothing else reads: the clock the
+//                part holds UNDER THIS KERNEL (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+template <int FMT, bool HIST, int TILES, int MATH, bool BURST, bool MULTI, bool STAMP = false>
 __device__ __forceinline__ void
 rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, uint32_t W, uint32_t H, uint32_t unit0,
               uint32_t unit1, uint32_t tpu, uint32_t tpu_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
               const rd_ku &u_arg, uint32_t *slab32, unsigned long long *slab64,
-              const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t tpf, uint32_t tpf_magic)
+              const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t tpf, uint32_t tpf_magic,
+              uint32_t *stamps = nullptr)
 {
     // Register budget: two workgroups per CU need <= 80 SGPRs AND <= 64 VGPRs per wave (RD_NUM_SGPR above).  The uniforms of
     // the front of the stack (white balance, temperature/tint, matrix) and of the levels divide (17 values) are therefore parked in VGPRs -- the asm
@@ -970,6 +982,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         sa[3] = 1.0f; sa[7] = 1.0f; sa[11] = 1.0f;
         __builtin_amdgcn_wave_barrier();
     }
+    uint64_t stamp_t0 = 0, stamp_r0 = 0;
+    if constexpr (STAMP) { stamp_t0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
 #ifdef RD_PROBE
     const uint64_t probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t probe_tiles = 0;
@@ -1191,7 +1205,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         c3 = RD_COLOUR(u, C, D, B);
 #else
         float tr[3] = { C, C, C }, tg[3] = { A, D, D }, tb[3] = { B, A, B };       // row a: (C,A,B); row b: (C,D,A), (C,D,B)
-        rd_colour_n<3, MATH, !(Q8ONLY || H16 || F32T)>(u, tr, tg, tb);
+        if constexpr (MATH != RD_MATH_PROBE) rd_colour_n<3, MATH, !(Q8ONLY || H16 || F32T)>(u, tr, tg, tb);
         c1 = rd_rgb{ tr[0], tg[0], tb[0] }; c2 = rd_rgb{ tr[1], tg[1], tb[1] }; c3 = rd_rgb{ tr[2], tg[2], tb[2] };
 #endif
         if constexpr (Q8ONLY) {
@@ -1223,6 +1237,11 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             // holds the PREVIOUS tile until store_tile has read it -- which the loop does before it computes this one, and
             // a wave's LDS operations execute in order.
             rd_f4 *st = stage + (size_t)wave * 192u;
+            if constexpr (MATH == RD_MATH_PROBE) {                // the pattern probe: the samples as they are, nothing counted
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = c1;
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 1u]) = c2;
+                *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = c3;
+            } else {
             const rd_rgb g1 = { rd_gamma_clamp(c1.r), rd_gamma_clamp(c1.g), rd_gamma_clamp(c1.b) };
             if (HIST && valid && has_a) count(rd_q8(g1.r), rd_q8(g1.g), rd_q8(g1.b), 2u);
             *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 0u]) = g1;
@@ -1232,6 +1251,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             const rd_rgb g3 = { rd_gamma_clamp(c3.r), rd_gamma_clamp(c3.g), rd_gamma_clamp(c3.b) };
             if (HIST && valid && has_b) count(rd_q8(g3.r), rd_q8(g3.g), rd_q8(g3.b), 1u);
             *reinterpret_cast<rd_rgb *>(&st[lane * 3u + 2u]) = g3;
+            }
         } else if (HIST || FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8) {
             q1r = rd_q8(c1.r); q1g = rd_q8(c1.g); q1b = rd_q8(c1.b);
             q2r = rd_q8(c2.r); q2g = rd_q8(c2.g); q2b = rd_q8(c2.b);
@@ -1530,6 +1550,12 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         (void)draw();                                            // launch smaller than the grid: still one (failed) draw per wave
     }
     if (HIST) rd_hist_flush(lh, slab32, slab64);
+    if constexpr (STAMP) {
+        if (threadIdx.x == 0 && stamps) {
+            stamps[blockIdx.x * 2u + 0u] = (uint32_t)(__builtin_amdgcn_s_memtime() - stamp_t0);
+            stamps[blockIdx.x * 2u + 1u] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - stamp_r0);
+        }
+    }
 #ifdef RD_PROBE
     if (lane == 0) atomicAdd(&rd_probe_buf[blockIdx.x * 8u + 6u], probe_tiles + (tile < ntiles ? 1u : 0u));
     if (threadIdx.x == 0) {
@@ -1559,14 +1585,14 @@ rd_develop_quads(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint3
 // `nframes` whole frames of one size per launch (descs[0 .. nframes-1], frame-major tile index; tpf = tiles per
 // frame): the batch path.  Histogram counts of all frames meet in the workgroup's LDS table (u32: the host keeps
 // nframes * W * H below 2^32) and are added to its u64 slab row at the end of the launch.
-template <int FMT, bool HIST, int TILES, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32)>
+template <int FMT, bool HIST, int TILES, int MATH = RD_MATH_STRICT, bool BURST = (FMT == RD_FMT_RGBA_F32), bool STAMP = false>
 __global__ void __launch_bounds__(RD_BLOCK) __attribute__((amdgpu_num_sgpr(RD_NUM_SGPR))) RD_WAVES_PER_EU
 rd_develop_batch(const rd_frame_desc *__restrict__ descs, uint32_t nframes, uint32_t W, uint32_t H, uint32_t tpu,
                  uint32_t tpu_magic, uint32_t tpf, uint32_t tpf_magic, uint32_t tq_k, uint32_t tq_tmax, uint32_t *tq,
-                 unsigned long long *slab64)
+                 unsigned long long *slab64, uint32_t *stamps)
 {
-    rd_quads_body<FMT, HIST, TILES, MATH, BURST, true>(nullptr, nullptr, W, H, 0u, H / 2u + 1u, tpu, tpu_magic, tq_k, tq_tmax, tq,
-                                                      descs[0].u, nullptr, slab64, descs, nframes, tpf, tpf_magic);
+    rd_quads_body<FMT, HIST, TILES, MATH, BURST, true, STAMP>(nullptr, nullptr, W, H, 0u, H / 2u + 1u, tpu, tpu_magic, tq_k, tq_tmax, tq,
+                                                             descs[0].u, nullptr, slab64, descs, nframes, tpf, tpf_magic, stamps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1683,10 +1709,14 @@ __global__ void __launch_bounds__(RD_FOLD_THREADS) rd_reduce_slab32(uint32_t *__
     if (threadIdx.x < 32u) out32[blockIdx.x * 32u + threadIdx.x] = tot;
 }
 
-// dst[0..768) = src[0..768): a device's folded histogram into page-locked host memory (rd_node_batch_histogram_enqueue).
-__global__ void __launch_bounds__(768) rd_copy_hist64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst)
+// acc[0..768) += src[0..768); dst = acc: a device's folded histogram interval added to its running sum (everything enqueued
+// since the last fetch), the sum stored into page-locked host memory (rd_node_batch_histogram_enqueue).
+__global__ void __launch_bounds__(768) rd_acc_hist64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ acc,
+                                                     unsigned long long *__restrict__ dst)
 {
-    dst[threadIdx.x] = src[threadIdx.x];
+    const unsigned long long v = acc[threadIdx.x] + src[threadIdx.x];
+    acc[threadIdx.x] = v;
+    dst[threadIdx.x] = v;
     __threadfence_system();
 }
 

@@ -25,6 +25,72 @@ def test_child_environment():
     assert bench.child_env({}, 0, 2, 1)["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"   # set when the shell did not export it
 
 
+def test_every_rank_sees_only_its_own_gpu():
+    """VERDICT round 5, item 2 (the process guard): under the default RAWDEV_RANK_VISIBILITY=own the children of the
+    self-launcher -- and a rank started by torch.distributed.run, through the same function -- narrow their own view to one
+    card before anything touches the GPU; `all` keeps the launcher's view."""
+    base = {"PATH": "/bin"}
+    envs = [bench.child_env(base, r, 8, 29511, n_gpus=8) for r in range(8)]
+    assert [e["ROCR_VISIBLE_DEVICES"] for e in envs] == [str(r) for r in range(8)]           # no list set: card LOCAL_RANK
+    assert all(e["RAWDEV_RANK_NARROWED"] == "1" and "HIP_VISIBLE_DEVICES" not in e for e in envs)
+    assert "ROCR_VISIBLE_DEVICES" not in base
+    # a rehearsal with more ranks than cards (four gloo ranks on a one-GPU box): every rank gets the one card
+    assert [bench.child_env(base, r, 4, 1, n_gpus=1)["ROCR_VISIBLE_DEVICES"] for r in range(4)] == ["0"] * 4
+    # a list the launcher has set is indexed, whichever variable carries it; the lowest layer wins
+    e = bench.child_env({"HIP_VISIBLE_DEVICES": "4,5,6,7"}, 2, 4, 1, n_gpus=8)
+    assert e["HIP_VISIBLE_DEVICES"] == "6" and "ROCR_VISIBLE_DEVICES" not in e
+    e = bench.child_env({"ROCR_VISIBLE_DEVICES": "1,3", "HIP_VISIBLE_DEVICES": "0,1"}, 1, 2, 1, n_gpus=8)
+    assert e["ROCR_VISIBLE_DEVICES"] == "3" and e["HIP_VISIBLE_DEVICES"] == "0,1"
+    # a launcher that narrowed already (one entry) is left alone
+    e = bench.child_env({"HIP_VISIBLE_DEVICES": "5"}, 3, 8, 1, n_gpus=8)
+    assert e["HIP_VISIBLE_DEVICES"] == "5" and "ROCR_VISIBLE_DEVICES" not in e and "RAWDEV_RANK_NARROWED" not in e
+    # the switch: every rank keeps the launcher's view
+    e = bench.child_env({"RAWDEV_RANK_VISIBILITY": "all"}, 3, 8, 1, n_gpus=8)
+    assert not any(v in e for v in bench.VISIBILITY_VARS) and "RAWDEV_RANK_NARROWED" not in e
+    # the LOCAL_RANK branch of run_ranks calls the same function on os.environ: a child the self-launcher narrowed is not
+    # narrowed twice (its one-entry list would be indexed with its rank otherwise), a torchrun rank is
+    env = dict(envs[5])
+    info = bench.narrow_visibility(env, 5, n_gpus=8)
+    assert env["ROCR_VISIBLE_DEVICES"] == "5" and info["variable"] == "ROCR_VISIBLE_DEVICES" and info["value"] == "5"
+    env = {"LOCAL_RANK": "5"}
+    info = bench.narrow_visibility(env, 5, n_gpus=8)
+    assert env["ROCR_VISIBLE_DEVICES"] == "5" and info["mode"] == "own" and info["physical_gpus"] == 8
+    assert bench.physical_gpu_count() >= 0                        # no KFD topology in this container: 0, never an exception
+
+
+def test_launch_summary_splits_kernel_time_from_gaps():
+    """The per-launch account of round 6: launches of 100 us at positions 0 and 1 of three steps, 5 us between them, 40 us
+    across a step boundary."""
+    tl, t = [], 0.0
+    for call in range(3):
+        for pos in range(2):
+            dur = 100.0 + pos                                     # position 1 is 1 us slower, step after step
+            tl.append((call, t, t + dur))
+            t += dur + (5.0 if pos == 0 else 40.0)
+    su = bench.launch_summary(tl, alg_bytes_per_launch=1e6)
+    assert su["steps"] == 3 and su["launches_per_step"] == 2
+    assert su["launch_us_by_position"] == [100.0, 101.0]
+    assert su["launch_us"] == {"min": 100.0, "median": 100.5, "max": 101.0, "mean": 100.5}
+    assert abs(su["kernel_ms_per_step"] - 0.201) < 1e-9
+    assert su["gap_us_between_launches"]["median"] == 5.0 and su["step_boundary_gap_us"]["median"] == 40.0
+    assert abs(su["instrumented_ms_per_step"] - 0.246) < 1e-9
+    assert su["GBps_median_launch"] == round(1e6 / 100.5e-6 / 1e9, 1)
+    assert bench.launch_summary([]) is None
+
+
+def test_clock_source_reports_why_it_is_unavailable():
+    """No GPU driver here: neither amdsmi nor sysfs can serve; the line then carries null and the reasons, never an exception
+    (and never a new dependency)."""
+    fn, why = bench.open_clock_source("0000:c1:00.0")
+    assert fn is None and "sysfs" in why
+    smp = bench.ClockSampler(lambda: {"sclk_MHz": 2100.0, "power_W": 700.0}, period_s=0.001)
+    with smp:
+        import time
+        time.sleep(0.02)
+    out = smp.summary()
+    assert out["samples"] >= 2 and out["sclk_MHz"]["median"] == 2100.0 and out["power_W"]["max"] == 700.0
+
+
 def test_argument_defaults_and_modes():
     a = bench.parse_args([])
     assert (a.gpus, a.steps, a.warmup, a.frames, a.host, a.static_descriptors) == (1, 20, 3, 256, "ranks", False)

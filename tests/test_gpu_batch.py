@@ -251,3 +251,140 @@ def test_same_batch_on_two_streams_in_turn(gpu_lib, refc):
     for s in streams:
         check(_lib.lib().rd_stream_destroy(0, C.c_void_p(s)))
     be.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the measurement aids behind bench.py's self-diagnosis (rd_batch_set_launch_timing / _launch_timeline,
+# rd_batch_probe_pattern, rd_batch_measure_clock)
+# ------------------------------------------------------------------------------------------------
+def _taps_np(cfa):
+    """tests.helpers.expected_taps (the SURVEY 8 a2 table), vectorised: (h, w, 3) float32 of raw / 4096."""
+    h, w = cfa.shape
+    yy, xx = np.mgrid[0:h, 0:w]
+
+    def at(y, x):
+        return cfa[np.clip(y, 0, h - 1), np.clip(x, 0, w - 1)].astype(np.float32) / np.float32(4096.0)
+    odd, ecol = (yy % 2 == 1), (xx % 2 == 0)
+    r = np.where(odd & ecol, at(yy + 1, xx), np.where(odd, at(yy + 1, xx - 1), np.where(ecol, at(yy, xx), at(yy, xx - 1))))
+    g = np.where(odd & ecol, at(yy, xx), np.where(odd, at(yy, xx - 1), np.where(ecol, at(yy, xx + 1), at(yy, xx))))
+    b = np.where(odd & ecol, at(yy, xx + 1), np.where(odd, at(yy, xx), at(yy - 1, xx)))
+    return np.stack([r, g, b], axis=-1).astype(np.float32)
+
+
+def test_launch_timeline_keeps_the_last_calls(gpu_lib, refc):
+    ra = gpu_lib
+    from tests.helpers import expected_taps
+    small = random_cfa(np.random.default_rng(3), 5, 6)
+    assert np.array_equal(_taps_np(small), (expected_taps(small) / 4096.0).astype(np.float32))     # the helper above, against the table
+    h, w, n = 66, 256, 20                                       # 20 frames, at most 8 per launch: 3 launches per call
+    rng = np.random.default_rng([6, h, w])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    d_out = [DevBuf(h * w * 16) for _ in range(n)]
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, True)
+    frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
+    assert be.launch_timeline() == []                            # off by default
+    be.develop(frames)
+    sync()
+    assert be.launch_timeline() == []
+    be.set_launch_timing(2)
+    for _ in range(3):
+        be.develop(frames)
+    sync()
+    tl = be.launch_timeline()
+    per_call = be.last_launch_count()
+    assert per_call == 3 and len(tl) == 2 * per_call             # the window holds the last two of the three calls
+    assert [c for c, _, _ in tl] == [0] * per_call + [1] * per_call
+    assert tl[0][1] == 0.0
+    for i, (_, st, en) in enumerate(tl):
+        assert en > st >= 0.0, tl
+        if i:
+            assert st >= tl[i - 1][2] - 1e-3, tl                 # one stream: a launch starts after its predecessor ended
+    u = refc.make_uniforms({f: getattr(params[7], f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+    assert np.array_equal(d_out[7].to_array(np.float32, (h, w, 4)).view(np.uint32), refc.render_f32(cfas[7], u).view(np.uint32))   # timed launches are ordinary launches
+    be.set_launch_timing(0)
+    assert be.launch_timeline() == []
+    be.develop(frames)
+    sync()
+    assert be.launch_timeline() == []
+    with pytest.raises(ra.RawdevError):
+        be.set_launch_timing(65)
+    be.close()
+
+
+def test_pattern_probe_moves_the_kernels_bytes_without_its_arithmetic(gpu_lib, refc):
+    """rd_batch_probe_pattern: the f32 export kernel's loads, sweeps, tickets, LDS stage and stores with the colour stack, the
+    gamma and the histogram removed -- every pixel receives its three demosaic taps as raw / 4096 and alpha 1; the histogram
+    accumulator is not touched; a develop on the same context afterwards is an ordinary develop."""
+    ra = gpu_lib
+    h, w, n = 1026, 1024, 3                                     # (h / 2 + 1) * w >= 2^19: the read-burst instance takes it
+    rng = np.random.default_rng([66, h, w])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    d_out = [DevBuf(h * w * 16) for _ in range(n)]
+    d_hist = DevBuf(768 * 8)
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, True)
+    frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
+    be.set_launch_timing(1)
+    be.probe_pattern(frames)
+    sync()
+    assert len(be.launch_timeline()) == be.last_launch_count() == 1
+    be.set_launch_timing(0)
+    for c, o in zip(cfas, d_out):
+        got = o.to_array(np.float32, (h, w, 4))
+        assert np.array_equal(got[..., :3], _taps_np(c)) and np.all(got[..., 3] == 1.0)
+    be.develop(frames)
+    be.histogram(d_hist.ptr)
+    sync()
+    exp_hist = np.zeros(768, np.uint64)
+    for c, p, o in zip(cfas, params, d_out):
+        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+        e = refc.render_f32(c, u)
+        assert np.array_equal(o.to_array(np.float32, (h, w, 4)).view(np.uint32), e.view(np.uint32))
+        exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
+    assert np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist)      # the probe counted nothing
+    be.close()
+    # what the probe is not built for is refused, not approximated
+    be8 = ra.BatchExporter(0, w, h, ra.FMT_RGBA_U8, True)
+    with pytest.raises(ra.RawdevError) as ei:
+        be8.probe_pattern(frames)
+    assert ei.value.code == -5
+    be8.close()
+    small = ra.BatchExporter(0, 64, 34, ra.FMT_RGBA_F32, True)
+    s_in, s_out = DevBuf.from_array(random_cfa(rng, 34, 64)), DevBuf(34 * 64 * 16)
+    with pytest.raises(ra.RawdevError) as ei:
+        small.probe_pattern(small.make_frames([s_in.ptr], [s_out.ptr], params[:1], WB_DAYLIGHT, CM_TEST))
+    assert ei.value.code == -5
+    small.close()
+
+
+def test_measure_clock_is_an_ordinary_develop_that_also_reads_the_clock(gpu_lib, refc):
+    ra = gpu_lib
+    h, w, n = 1026, 1024, 9                                     # two launches (8 + 1 frames): the LAST one's stamps are reported
+    rng = np.random.default_rng([67, h, w])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    d_out = [DevBuf(h * w * 16) for _ in range(n)]
+    d_hist = DevBuf(768 * 8)
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, True)
+    frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST)
+    ghz, lo, hi, busy_us = be.measure_clock(frames)
+    assert 0.3 < lo <= ghz <= hi < 3.5 and busy_us > 0.0, (ghz, lo, hi, busy_us)
+    be.histogram(d_hist.ptr)
+    sync()
+    exp_hist = np.zeros(768, np.uint64)
+    for c, p, o in zip(cfas, params, d_out):
+        u = refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST)
+        e = refc.render_f32(c, u)
+        assert np.array_equal(o.to_array(np.float32, (h, w, 4)).view(np.uint32), e.view(np.uint32))
+        exp_hist += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
+    assert np.array_equal(d_hist.to_array(np.uint64, (768,)), exp_hist)
+    be.close()
+    nohist = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, False)
+    with pytest.raises(ra.RawdevError) as ei:
+        nohist.measure_clock(frames)
+    assert ei.value.code == -5
+    nohist.close()

@@ -135,7 +135,8 @@ def test_node_batch_rejects_bad_arguments(gpu_lib):
 
 def test_histogram_in_two_halves(gpu_lib, refc, monkeypatch):
     """rd_node_batch_histogram_enqueue / _fetch (round 5): the fold, the reduction and the read-back are enqueued behind the
-    develop call, the next develop call is enqueued behind them without a drain, and fetch hands out the LAST enqueue's sum;
+    develop call, the next develop call is enqueued behind them without a drain, and fetch hands out the sum of EVERY interval
+    enqueued since the last fetch (ABI 5: round 5 returned the last interval and dropped the others -- ADVICE round 5);
     N = 1 (no exchange) and the one-GPU rehearsal of N = 3 with the host fold."""
     ra = gpu_lib
     h, w, n = 130, 256, 6
@@ -155,13 +156,16 @@ def test_histogram_in_two_halves(gpu_lib, refc, monkeypatch):
             nb.histogram_enqueue()
         nb.develop(half)
         nb.histogram_enqueue()
-        got = nb.histogram_fetch().reshape(-1)                    # the last enqueue: the three frames of `half`
+        got = nb.histogram_fetch().reshape(-1)                    # four intervals: three whole batches + the three frames of `half`
         exp_half = np.zeros(768, np.uint64)
         for e in exp[:3]:
             exp_half += refc.histogram(refc.pack_u8(e)).reshape(-1).astype(np.uint64)
-        assert np.array_equal(got, exp_half), devices
+        assert np.array_equal(got, 3 * exp_hist.reshape(-1).astype(np.uint64) + exp_half), devices
         with pytest.raises(ra.RawdevError):
-            nb.histogram_fetch()                                  # one fetch per enqueue
+            nb.histogram_fetch()                                  # nothing enqueued since that fetch
+        nb.develop(half)                                          # the running sums started again with the fetch
+        nb.histogram_enqueue()
+        assert np.array_equal(nb.histogram_fetch().reshape(-1), exp_half), devices
         nb.develop(frames)
         assert np.array_equal(nb.histogram().reshape(-1), exp_hist), devices     # the one-call form still synchronises and resets
         nb.synchronize()

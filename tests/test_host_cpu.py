@@ -84,7 +84,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"librawdev.so does not export {n}"
     assert sorted(_lib.PROTOTYPES) == names, "python prototypes out of sync with include/rawdev.h"
-    assert L.rd_abi_version() == _lib.ABI_VERSION == 4
+    assert L.rd_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_struct_layouts_match_header():

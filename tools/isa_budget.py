@@ -148,11 +148,13 @@ def extract_function(asm_lines, mangled_prefix):
 
 
 def mangle(template_args):
-    """'<2,true,1,0,false>' -> _Z16rd_develop_batchILi2ELb1ELi1ELi0ELb0EE  (FMT, HIST, TILES, MATH, BURST; the round-4
+    """'<2,true,1,0,false>' -> _Z16rd_develop_batchILi2ELb1ELi1ELi0ELb0ELb0EE  (FMT, HIST, TILES, MATH, BURST[, STAMP]; the round-4
     spelling '<2,true,true,0,false>' -- TILES was a bool then -- still names the abutting-tiles instance)"""
     parts = [p.strip() for p in template_args.strip("<>").split(",")]
     if len(parts) > 2 and parts[2] in ("true", "false"):
         parts[2] = "1" if parts[2] == "true" else "0"
+    if len(parts) == 5:
+        parts.append("false")                  # round 6: the sixth parameter, STAMP (the clock-stamping diagnostic instance), defaults to false
     out = "_Z16rd_develop_batchI"
     for p in parts:
         if p in ("true", "false"):
