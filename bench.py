@@ -107,16 +107,24 @@ VISIBILITY_VARS = ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_
 
 
 def physical_gpu_count():
-    """GPUs of this machine WITHOUT touching HIP or torch.cuda: the KFD topology nodes that have SIMDs (CPU nodes have none).
-    0 when the topology cannot be read (no driver: this container)."""
+    """GPUs THIS process could open, WITHOUT touching HIP or torch.cuda: the KFD topology nodes that have SIMDs (CPU nodes have
+    none) and whose DRM render node can be opened -- sysfs shows every card of the host, a box that is a one-GPU slice of an
+    eight-GPU machine must count one (ROCr skips the nodes it cannot open in the same way, so ROCR_VISIBLE_DEVICES indexes
+    exactly these, in this order).  0 when nothing can be read (no driver: this container)."""
     import glob
     n = 0
-    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+    for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda q: int(q.split("/")[-2]) if q.split("/")[-2].isdigit() else 0):
         try:
-            for line in open(path):
-                if line.startswith("simd_count") and int(line.split()[1]) > 0:
-                    n += 1
-        except (OSError, ValueError, IndexError):
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            if minor < 0:
+                continue
+            fd = os.open("/dev/dri/renderD%d" % minor, os.O_RDWR)     # a DRM file descriptor, closed at once: no HIP, no KFD queue
+            os.close(fd)
+            n += 1
+        except (OSError, ValueError):
             continue
     return n
 

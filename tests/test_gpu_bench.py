@@ -50,6 +50,11 @@ def test_bare_multi_gpu_call_launches_its_own_ranks(gpu_lib):
         assert x["ms_per_step"] > 0 and x["ms_per_step_hip_events"] > 0 and x["launches"] > 0 and x["us_per_frame"] > 0 and x["MP_per_s"] > 0
         assert x["box_copy_GBps"] > 1000 and x["box_fill_GBps"] > 1000
     assert r["distinct_devices"] == 1                      # the rehearsal: both ranks share device 0 (allowed under gloo only)
+    for x in r["ranks"]:                                   # round 6: every rank narrowed its own view to ONE card before it touched the GPU
+        assert x["visibility"]["mode"] == "own" and x["visibility"]["variable"] == "ROCR_VISIBLE_DEVICES" and x["visibility"]["value"] == "0", x
+        assert x["devices_visible"] == 1 and x["device_index"] == 0
+        assert x["launch_us"]["median"] > 0 and x["kernel_ms_per_step"] > 0 and 0.3 < x["clock_under_kernel_GHz"] < 3.5
+    assert r["roofline"]["launches"]["steps"] == 6 and r["kernel_ms_per_step"] > 0
     assert 0 < r["per_gpu_MPps_min"] <= r["per_gpu_MPps_max"]
     assert r["env"]["RAWDEV_DIST_BACKEND"] == "gloo" and "HSA_ENABLE_IPC_MODE_LEGACY" in r["env"]
     assert "distinct_devices" in r["config"]["host"]
@@ -118,6 +123,24 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert r["ranks"][0]["pci_bus_id"] and r["distinct_devices"] == 1 and r["world_size_seen"] == 1
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and "march=native" in cb["build"] and cb["value_portable_O2_build"] > 0
+    # round 6: the line explains its own speed
+    la = rf["launches"]
+    assert la["steps"] == 6 and la["launches_per_step"] == r["config"]["launches_per_step"] == len(la["launch_us_by_position"]) == 2
+    assert 0 < la["launch_us"]["min"] <= la["launch_us"]["median"] <= la["launch_us"]["max"] and la["step_boundary_gap_us"]["median"] > 0
+    assert r["kernel_ms_per_step"] > 0 and r["gap_ms_per_step"] is not None and 0 < rf["frac_kernel"] < 1
+    assert abs(r["kernel_ms_per_step"] + r["gap_ms_per_step"] - r["ms_per_step"]) < 1e-3
+    assert rf["box_before"]["copy"] > 3000 and rf["box_after"]["copy"] > 3000
+    assert rf["box_before"]["valu_effective_GHz"] > 0.5 and rf["box_after"]["valu_effective_GHz"] > 0.5
+    ck = r["clock_under_kernel_GHz"]
+    assert 0.3 < ck["GHz_min"] <= ck["GHz_median"] <= ck["GHz_max"] < 3.5, ck
+    assert (r["clocks"] and r["clocks"]["samples"] > 0 and r["clocks"]["source"]) or r["clocks_reason"], (r["clocks"], r["clocks_reason"])
+    assert rf["box_pattern_GBps"] > 1000 and 0 < rf["frac_of_box_pattern"] < 1.3 and rf["box_pattern"]["launch_us"]["median"] > 0
+    ab = r["descriptor_upload_ab"]
+    assert ab["rotating_ms_per_step"] > 0 and ab["static_ms_per_step"] > 0 and len(ab["rotating_all"]) == 3
+    assert ex["batch_rgba8"]["launches"]["launch_us"]["median"] > 0 and ex["batch_rgba8"]["kernel_ms_per_step"] > 0
+    assert ex["config5_shape_f16"]["launches"]["launches_per_step"] == ex["config5_shape_f16"]["launches_per_step"]
+    q = _bench(["--frames", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-diagnose"], {})
+    assert q["verified"] is True and q["kernel_ms_per_step"] is None and q["roofline"]["launches"] is None and q["clocks"] is None
 
 
 def test_measure_hbm_sizes(gpu_lib):
