@@ -504,7 +504,7 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     c.tq_tmax = c.tq_k ? (ndyn + c.tq_k - 1u) / c.tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;   // A/B override: 0 / 1
     // read burst (rd_kernels.h): f32 surface by default; needs 16-byte aligned CFA rows and a launch worth it
-    const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
+    const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (W % 2u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
     const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && (burst_env < 0 || burst_env != 0);
     c.blocks = blocks; c.cfa = cfa; c.out = out; c.W = W; c.H = H; c.unit0 = unit0; c.unit1 = unit1; c.tq = tq;
     c.slab32 = slab32; c.slab64 = slab64;
@@ -519,7 +519,20 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
         if (burst && tiles == RD_TILES_OVERLAP) c.fn = (const void *)rd_develop_quads<FMT, HIST, RD_TILES_OVERLAP, MATH, true>;
     }
     c.bind();
-    if (!record) (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
+    if (!record) {
+        (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
+        if (W & 1u) {
+            // odd width: the quads above cover columns [0, W - 1); the last column of the band's rows follows on the same
+            // stream (rd_develop_lastcol), its histogram counts added to the slab rows just written
+            const uint32_t row0 = unit0 ? 2u * unit0 - 1u : 0u;
+            const uint32_t row1 = 2u * (unit1 - 1u) + 1u < H ? 2u * (unit1 - 1u) + 1u : H;
+            if (row1 > row0) {
+                const uint32_t need = (row1 - row0 + 255u) / 256u;
+                hipLaunchKernelGGL((rd_develop_lastcol<FMT, HIST, MATH>), dim3(need < blocks ? need : blocks), dim3(256), 0, s, cfa, out,
+                                   (const rd_frame_desc *)nullptr, 1u, W, H, row0, row1, c.u, slab32, slab64);
+            }
+        }
+    }
 }
 
 // Does a multi-frame launch of W x H frames take the read-burst instance (f32 surface)?  The pattern probe
@@ -576,10 +589,16 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
         }
     }
     if constexpr (MATH == RD_MATH_PROBE) return;                 // (the probe has burst instances only: rd_probe_launchable)
-    else
-    if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
-    else if (tiles == RD_TILES_OVERLAP) RD_LAUNCH_BATCH(RD_TILES_OVERLAP, false);
-    else RD_LAUNCH_BATCH(RD_TILES_MASKED, false);
+    else {
+        if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
+        else if (tiles == RD_TILES_OVERLAP) RD_LAUNCH_BATCH(RD_TILES_OVERLAP, false);
+        else RD_LAUNCH_BATCH(RD_TILES_MASKED, false);
+        if (W & 1u) {                                            // odd width (never a burst launch): the frames' last column, all rows
+            const uint64_t need = ((uint64_t)nframes * H + 255u) / 256u;
+            hipLaunchKernelGGL((rd_develop_lastcol<FMT, HIST, MATH>), dim3((uint32_t)(need < blocks ? need : blocks)), dim3(256), 0, s,
+                               (const uint16_t *)nullptr, (void *)nullptr, descs_dev, nframes, W, H, 0u, H, rd_ku{}, (uint32_t *)nullptr, slab64);
+        }
+    }
 #undef RD_LAUNCH_BATCH
 }
 

@@ -88,7 +88,6 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
-    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "batch export needs an even frame width (got %u)", w);
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
     if (fmt == RD_FMT_RGB_U8 && w < 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs a frame at least 128 pixels wide (got %u)", w);
     const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
@@ -948,7 +947,6 @@ extern "C" int rd_exporter_create(int device, uint32_t w, uint32_t h, uint32_t f
     if (!out) return rd_fail(RD_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!w || !h || !n_slots || n_slots > 64) return rd_fail(RD_ERR_INVALID_ARG, "bad frame size or slot count");
-    if (w % 2u) return rd_fail(RD_ERR_UNSUPPORTED, "export needs an even frame width (got %u)", w);
     const size_t bpp = rd_format_bytes_per_pixel(fmt);
     if (!bpp) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
     if (fmt == RD_FMT_RGB_U8 && w < 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 export needs a frame at least 128 pixels wide (got %u)", w);

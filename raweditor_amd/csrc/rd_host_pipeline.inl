@@ -323,7 +323,8 @@ static rd_shot rd_pipeline_snapshot(rd_pipeline *p)
 static bool rd_pipeline_uses_quads(const rd_pipeline *p, const rd_shot &sh, uint32_t tw, uint32_t th, uint32_t fmt)
 {
     const uint32_t W = p->info.width, H = p->info.height;
-    return tw == W && th == H && sh.export_view && (W % 2u) == 0 && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
+    // (any width, odd ones too since round 6: the export kernel takes the whole quads and rd_develop_lastcol the last column)
+    return tw == W && th == H && sh.export_view && p->identity_ok && ((uintptr_t)p->cfa % 4u) == 0 &&
            (fmt != RD_FMT_RGB_U8 || W >= 128u) && !getenv("RD_FORCE_MAP");     // (RGB8 narrower than one tile: the map kernel's byte stores)
 }
 
@@ -342,7 +343,7 @@ static int rd_pipeline_enqueue(rd_pipeline *p, const rd_shot &sh, uint32_t tw, u
     const rd_scratch::lease l = p->scratch.get(s, hist_dev != nullptr);     // this stream's counters (+ slab)
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     static const bool use_graph = rd_env_u32("RD_GRAPH", 0) != 0;
-    if (use_graph && quads && hist_dev && unit0 == 0u && unit1 == H / 2u + 1u) {
+    if (use_graph && quads && hist_dev && unit0 == 0u && unit1 == H / 2u + 1u && (W % 2u) == 0) {
         rd_quads_call call;
         int rc = rd_enqueue_render(p->cfg, p->cfa, W, H, tw, th, fmt, dst_dev, sh.u, true, unit0, unit1, true, sh.math_mode,
                                    l.slab32, nullptr, 0, l.tq, s, &blocks, &call);

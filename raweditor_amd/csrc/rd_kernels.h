@@ -769,7 +769,8 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 //     row a (py odd),  both columns : (r,g,b) = (C, A, B)
 //     row b (py even), column 2q    : (r,g,b) = (C, D, A)     <- blue taken from a green site
 //     row b (py even), column 2q+1  : (r,g,b) = (C, D, B)
-// Requires W even and cfa 4-byte aligned (the host falls back to rd_develop_map otherwise).
+// Requires cfa 4-byte aligned (the host falls back to rd_develop_map otherwise).  An odd W leaves column W - 1 to
+// rd_develop_lastcol (below): the lanes here own the W / 2 whole quads of a row pair.
 //
 // Scheduling: a WAVE owns a tile = 64 consecutive quads of one unit (128 px x 2 rows).  Every wave
 // starts on tile `slot` (static) and then draws further tiles from a ticket counter with a SCALAR
@@ -1066,17 +1067,21 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
 #ifdef RD_PROBE_NO_TILE_LOADS                                    // probe builds only (tools/): what the main loop's loads cost the memory system
         (void)ra; (void)rb; top = lane * 0x00010001u + pu; bot = top ^ 0x01230123u; return;
 #endif
+        // (a quad's two samples are ONE dword load.  With an odd W every other row starts on an odd 16-bit boundary, so the
+        //  dword is declared 2-byte aligned: gfx950 under HSA runs with unaligned global access, hipcc keeps global_load_dword
+        //  and the even widths' code does not change -- tools/isa_budget.py before / after)
+        typedef uint32_t rd_u32_a2 __attribute__((aligned(2)));
         if constexpr (FULL) {
             // wave-uniform base (SALU, 64-bit) + the lane's own dword: global_load_dword v_lane4, s[base] -- no per-tile
             // 64-bit VALU address arithmetic (it was 14 issue cycles per tile, tools/isa_budget.py)
             const size_t x0 = (size_t)qbase(pq) * 2u;
-            top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)ra * W + x0))[lane];
-            bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + ((size_t)rb * W + x0))[lane];
+            top = reinterpret_cast<const RD_GLOBAL rd_u32_a2 *>(cfa + ((size_t)ra * W + x0))[lane];
+            bot = reinterpret_cast<const RD_GLOBAL rd_u32_a2 *>(cfa + ((size_t)rb * W + x0))[lane];
         } else {
             uint32_t q = pq * 64u + lane;
             q = q < qpr ? q : qpr - 1u;                          // clamp: loaded but never used
-            top = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)ra * W)[q];
-            bot = reinterpret_cast<const RD_GLOBAL uint32_t *>(cfa + (size_t)rb * W)[q];
+            top = reinterpret_cast<const RD_GLOBAL rd_u32_a2 *>(cfa + (size_t)ra * W)[q];
+            bot = reinterpret_cast<const RD_GLOBAL rd_u32_a2 *>(cfa + (size_t)rb * W)[q];
         }
     };
 
@@ -1317,7 +1322,7 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
                 const uint32_t jb = ja + 1u + (p & 1u);                // row b: c2 (even col) / c3 (odd col)
                 const rd_f4 va = st[has_a ? ja : jb];                  // a missing row re-stores the other one: the select is
                 const rd_f4 vb = st[has_b ? jb : ja];                  // made on the LDS index (2 per half), not on 8 floats
-                if (FULL || px < W) {
+                if (FULL || px < 2u * qpr) {                           // (an odd W: column W - 1 is rd_develop_lastcol's)
                     // wave-uniform base (row + the tile's first column: SALU) + the lane's own pixel, like the loads
 #ifdef RD_ST_PLAIN
                     (o + (row_a_px + (size_t)q0 * 2u))[p] = va;
@@ -1330,15 +1335,19 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             }
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (FMT == RD_FMT_RGBA_F16) {
-            RD_GLOBAL rd_u4 *o = reinterpret_cast<RD_GLOBAL rd_u4 *>(out);   // 2 px = 16 B per lane per row
+            // 2 px = 16 B per lane per row.  A row starts at pixel row * W: 8-byte aligned for every W, 16-byte aligned only when
+            // row * W is even -- so the address is formed in pixels and the 16-byte store is declared 8-byte aligned (one
+            // global_store_dwordx4 either way)
+            typedef rd_u4 rd_u4_a8 __attribute__((aligned(8)));
+            RD_GLOBAL rd_u2 *o = reinterpret_cast<RD_GLOBAL rd_u2 *>(out);
             rd_u4 va = { r.a0, r.a1, r.a0, r.a1 }, vb = { r.b0, r.b1, r.c0, r.c1 };
             if (__builtin_expect(!(has_a && has_b), 0)) {        // first / last unit only (wave-uniform): a BRANCH -- as selects
                 if (!has_a) va = vb; else vb = va;               // it cost every tile eight v_cndmask (the asm keeps it a branch)
                 asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
             }
             if (valid) {                                         // wave-uniform base + the lane's own 16 bytes (see load_tile)
-                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)q0) + lane);
-                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)q0) + lane);
+                __builtin_nontemporal_store(va, reinterpret_cast<RD_GLOBAL rd_u4_a8 *>(o + (row_a_px + (size_t)q0 * 2u)) + lane);
+                __builtin_nontemporal_store(vb, reinterpret_cast<RD_GLOBAL rd_u4_a8 *>(o + (row_b_px + (size_t)q0 * 2u)) + lane);
             }
         } else if constexpr (FMT == RD_FMT_RGB_U8) {
             // 2 px = 6 B per lane per row: repack the wave's 384-B rows through LDS (three 16-bit writes per
@@ -1359,29 +1368,38 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             s16[192u + lane * 3u + 2u] = (uint16_t)(pd >> 8);
             __builtin_amdgcn_wave_barrier();
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s16);
-            typedef uint32_t rd_u32_a2 __attribute__((aligned(2)));
-            RD_GLOBAL rd_u32_a2 *oa = reinterpret_cast<RD_GLOBAL rd_u32_a2 *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_a_px + (size_t)q0 * 2u) * 3u);
-            RD_GLOBAL rd_u32_a2 *ob = reinterpret_cast<RD_GLOBAL rd_u32_a2 *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_b_px + (size_t)q0 * 2u) * 3u);
+            // (an odd W puts every other row on an ODD byte: the dwords are declared 1-byte aligned)
+            typedef uint32_t rd_u32_a1 __attribute__((aligned(1)));
+            RD_GLOBAL rd_u32_a1 *oa = reinterpret_cast<RD_GLOBAL rd_u32_a1 *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_a_px + (size_t)q0 * 2u) * 3u);
+            RD_GLOBAL rd_u32_a1 *ob = reinterpret_cast<RD_GLOBAL rd_u32_a1 *>(reinterpret_cast<RD_GLOBAL uint8_t *>(out) + (row_b_px + (size_t)q0 * 2u) * 3u);
             const uint32_t a0 = s32[lane], b0 = s32[96u + lane];
             const uint32_t l2 = lane & 31u;
             const uint32_t a1 = s32[64u + l2], b1 = s32[160u + l2];
+#ifdef RD_RGB8_ST_PLAIN       // A/B build (tools/build_ab_libs.sh r6): write-back stores, so that the L2 may merge the two halves of a
+            oa[lane] = a0;         // 32-byte sector that a ragged row splits between neighbouring tiles (profiles/r06_rgb8_ragged_ab.txt)
+            ob[lane] = b0;
+            if (lane < 32u) { oa[64u + lane] = a1; ob[64u + lane] = b1; }
+#else
             __builtin_nontemporal_store(a0, oa + lane);
             __builtin_nontemporal_store(b0, ob + lane);
             if (lane < 32u) {
                 __builtin_nontemporal_store(a1, oa + 64u + lane);
                 __builtin_nontemporal_store(b1, ob + 64u + lane);
             }
+#endif
             __builtin_amdgcn_wave_barrier();
         } else {
-            RD_GLOBAL rd_u2 *o = reinterpret_cast<RD_GLOBAL rd_u2 *>(out);   // 2 px = 8 B per lane per row
+            // 2 px = 8 B per lane per row; formed in pixels and declared 4-byte aligned for the same reason
+            typedef rd_u2 rd_u2_a4 __attribute__((aligned(4)));
+            RD_GLOBAL uint32_t *o = reinterpret_cast<RD_GLOBAL uint32_t *>(out);
             rd_u2 va = { r.v1, r.v1 }, vb = { r.v2, r.v3 };
             if (__builtin_expect(!(has_a && has_b), 0)) {        // first / last unit only (wave-uniform): a branch, not selects
                 if (!has_a) va = vb; else vb = va;
                 asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(vb.x), "+v"(vb.y));
             }
             if (valid) {
-                __builtin_nontemporal_store(va, o + ((row_a_px >> 1) + (size_t)q0) + lane);
-                __builtin_nontemporal_store(vb, o + ((row_b_px >> 1) + (size_t)q0) + lane);
+                __builtin_nontemporal_store(va, reinterpret_cast<RD_GLOBAL rd_u2_a4 *>(o + (row_a_px + (size_t)q0 * 2u)) + lane);
+                __builtin_nontemporal_store(vb, reinterpret_cast<RD_GLOBAL rd_u2_a4 *>(o + (row_b_px + (size_t)q0 * 2u)) + lane);
             }
         }
     };
@@ -1608,6 +1626,32 @@ __device__ __forceinline__ float rd_tap(const uint16_t *cfa, int32_t W, int32_t 
     return rd_norm(cfa[(size_t)y * (size_t)W + (size_t)x], bl);
 }
 
+// One pixel (px, py) of the frame, inside it: the demosaic selection of shaders.rs:127-155 with get_neighbor's clamps and the
+// colour stack.  LINEAR = true stops before the gamma / clamp step (the 8-bit surfaces finish with rd_q8_gamma).  Shared by
+// rd_develop_map (after its pixel map) and rd_develop_lastcol (the last column of an odd-width frame).
+template <int MATH, bool LINEAR>
+__device__ __forceinline__ rd_rgb rd_develop_px(const uint16_t *cfa, int32_t W, int32_t H, int32_t px, int32_t py, const rd_ku &u)
+{
+    const float n = rd_tap(cfa, W, H, px, py, u.black_level);
+    const bool even_row = ((py + 1) & 1) == 0;   // shaders.rs:115-116
+    const bool even_col = (px & 1) == 0;
+    float r, g, b;
+    if (even_row) {
+        if (even_col) { g = n; b = rd_tap(cfa, W, H, px + 1, py, u.black_level); r = rd_tap(cfa, W, H, px, py + 1, u.black_level); }
+        else          { b = n; g = rd_tap(cfa, W, H, px - 1, py, u.black_level); r = rd_tap(cfa, W, H, px - 1, py + 1, u.black_level); }
+    } else {
+        if (even_col) { r = n; g = rd_tap(cfa, W, H, px + 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
+        else          { g = n; r = rd_tap(cfa, W, H, px - 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
+    }
+    if constexpr (LINEAR) {
+        float tr[1] = { r }, tg[1] = { g }, tb[1] = { b };
+        rd_colour_n<1, MATH, false>(u, tr, tg, tb);
+        return rd_rgb{ tr[0], tg[0], tb[0] };
+    } else {
+        return rd_colour_m<MATH>(u, r, g, b);
+    }
+}
+
 template <int FMT, bool HIST, int MATH = RD_MATH_STRICT>
 __global__ void __launch_bounds__(RD_BLOCK)
 rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_t W, uint32_t H,
@@ -1631,24 +1675,7 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
             int32_t py = (int32_t)(ty * (float)H);
             px = px > (int32_t)W - 1 ? (int32_t)W - 1 : px;
             py = py > (int32_t)H - 1 ? (int32_t)H - 1 : py;
-            const float n = rd_tap(cfa, W, H, px, py, u.black_level);
-            const bool even_row = ((py + 1) & 1) == 0;   // shaders.rs:115-116
-            const bool even_col = (px & 1) == 0;
-            float r, g, b;
-            if (even_row) {
-                if (even_col) { g = n; b = rd_tap(cfa, W, H, px + 1, py, u.black_level); r = rd_tap(cfa, W, H, px, py + 1, u.black_level); }
-                else          { b = n; g = rd_tap(cfa, W, H, px - 1, py, u.black_level); r = rd_tap(cfa, W, H, px - 1, py + 1, u.black_level); }
-            } else {
-                if (even_col) { r = n; g = rd_tap(cfa, W, H, px + 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
-                else          { g = n; r = rd_tap(cfa, W, H, px - 1, py, u.black_level); b = rd_tap(cfa, W, H, px, py - 1, u.black_level); }
-            }
-            if constexpr (Q8ONLY) {                    // linear values; rd_q8_gamma finishes (out-of-bounds pixels stay 0 -> code 0)
-                float tr[1] = { r }, tg[1] = { g }, tb[1] = { b };
-                rd_colour_n<1, MATH, false>(u, tr, tg, tb);
-                c = rd_rgb{ tr[0], tg[0], tb[0] };
-            } else {
-                c = rd_colour_m<MATH>(u, r, g, b);
-            }
+            c = rd_develop_px<MATH, Q8ONLY>(cfa, W, H, px, py, u);   // Q8ONLY: linear values; rd_q8_gamma finishes (out-of-bounds pixels stay 0 -> code 0)
         }
         uint32_t qr = 0, qg = 0, qb = 0;
         if constexpr (Q8ONLY) { qr = rd_q8_gamma(c.r); qg = rd_q8_gamma(c.g); qb = rd_q8_gamma(c.b); }
@@ -1657,6 +1684,52 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
         if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 1u);
     }
     if (HIST) rd_hist_flush(lh, slab32, slab64);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rd_develop_lastcol -- the last column of frames whose width is ODD (round 6: the reference renders any texture size,
+// shaders.rs:181-187, loader.rs:57-58; a cropped plane can have one).
+// The export kernel's lanes own 2 x 2 blocks, so it covers columns [0, W - 1) of such a frame (its row stride is W all the
+// same: rows then start on odd 16-bit boundaries, see load_tile).  Column W - 1 -- an even index, whose right-hand neighbour
+// clamps onto itself (shaders.rs:163-166) -- is one pixel per row: one lane per (frame, row) evaluates it with the map
+// kernel's per-pixel code (rd_develop_px: the same bits as every other path), stores it, and ADDS its histogram counts to the
+// slab rows the export kernel has just written.  Launched behind that kernel on its stream; rows [row0, row1) of `nframes`
+// frames (descs != nullptr: a multi-frame launch's descriptors; otherwise one frame from the arguments).
+// ---------------------------------------------------------------------------------------------
+template <int FMT, bool HIST, int MATH = RD_MATH_STRICT>
+__global__ void __launch_bounds__(256)
+rd_develop_lastcol(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, const rd_frame_desc *__restrict__ descs,
+                   uint32_t nframes, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, rd_ku u_arg, uint32_t *slab32,
+                   unsigned long long *slab64)
+{
+    constexpr bool Q8ONLY = FMT == RD_FMT_RGBA_U8 || FMT == RD_FMT_RGB_U8;
+    __shared__ uint32_t lh[HIST ? 768 * RD_HK : 1];
+    if (HIST) rd_hist_zero(lh);
+    const uint32_t copy = threadIdx.x & (RD_HK - 1);
+    const uint32_t rows = row1 - row0, total = nframes * rows;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const uint32_t f = idx / rows, y = row0 + (idx - f * rows);
+        const uint16_t *cfa = descs ? descs[f].cfa : cfa_arg;
+        void *out = descs ? descs[f].out : out_arg;
+        const rd_ku u = descs ? descs[f].u : u_arg;
+        const rd_rgb c = rd_develop_px<MATH, Q8ONLY>(cfa, (int32_t)W, (int32_t)H, (int32_t)W - 1, (int32_t)y, u);
+        uint32_t qr = 0, qg = 0, qb = 0;
+        if constexpr (Q8ONLY) { qr = rd_q8_gamma(c.r); qg = rd_q8_gamma(c.g); qb = rd_q8_gamma(c.b); }
+        else if (HIST) { qr = rd_q8(c.r); qg = rd_q8(c.g); qb = rd_q8(c.b); }
+        rd_store_px<FMT>(out, (size_t)y * W + (W - 1u), c, qr, qg, qb);
+        if (HIST) rd_hist_add(lh, copy, qr, qg, qb, 1u);
+    }
+    if (HIST) {                                                   // ADD to this workgroup's slab row (the export kernel wrote it)
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < 768u; t += blockDim.x) {
+            uint32_t sum = 0;
+#pragma unroll 8
+            for (uint32_t i = 0; i < RD_HK; ++i) sum += lh[t * RD_HK + ((t + i) & (RD_HK - 1))];
+            if (slab64) slab64[(size_t)blockIdx.x * 768u + t] += sum;
+            else slab32[(size_t)blockIdx.x * 768u + t] += sum;
+        }
+    }
 }
 
 // calculate_histogram (pipeline.rs:720-736) on an RGBA8 buffer of npx pixels.

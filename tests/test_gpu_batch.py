@@ -140,8 +140,9 @@ def test_multi_frame_launch_limits(gpu_lib, refc, monkeypatch):
 
 def test_batch_rejects_bad_arguments(gpu_lib):
     ra = gpu_lib
+    ra.BatchExporter(0, 7, 8, ra.FMT_RGBA_F32).close()           # odd width: taken since round 6 (tests/test_gpu_ragged.py)
     with pytest.raises(ra.RawdevError):
-        ra.BatchExporter(0, 7, 8, ra.FMT_RGBA_F32)               # odd width
+        ra.BatchExporter(0, 0, 8, ra.FMT_RGBA_F32)               # empty frame
     with pytest.raises(ra.RawdevError):
         ra.BatchExporter(0, 8, 8, 5)                             # unknown format
     be = ra.BatchExporter(0, 8, 8, ra.FMT_RGBA_F32, with_histogram=False)

@@ -205,3 +205,98 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: ODD widths.  The reference renders any texture size (shaders.rs:181-187, loader.rs:57-58); a cropped plane can be
+# an odd number of pixels wide.  The export kernel takes the W // 2 whole quads of every row pair (rows then start on odd
+# 16-bit boundaries: 2-byte aligned dword loads, byte-aligned RGB8 dword stores) and rd_develop_lastcol the last column; no
+# entry point refuses a width for its parity any more.
+# ------------------------------------------------------------------------------------------------
+SMALL_ODD = [(7, 131), (1, 129), (2, 131), (5, 191), (4, 257), (3, 385), (6, 1), (5, 3), (4, 7), (9, 127), (2, 65), (8, 193)]
+
+
+@pytest.mark.parametrize("math", [0, 1])
+def test_small_odd_width_frames_every_surface(gpu_lib, refc, math):
+    ra = gpu_lib
+    rng = np.random.default_rng([0x52415745, 6, math])
+    for h, w in SMALL_ODD:
+        cfa = random_cfa(rng, h, w, 65536)
+        for cm, params in ((CM_TEST, random_params(rng)), (CM_IDENTITY, {"exposure": 0.5, "contrast": 4.0})):
+            pipe = ra.RenderPipeline.new(1, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, cm)
+            pipe.set_math_mode(math)
+            u = refc.make_uniforms(params, WB_DAYLIGHT, cm, math_mode=math)
+            exp32 = refc.render_f32(cfa, u)
+            exp_hist = refc.histogram(refc.pack_u8(exp32))
+            for fmt in _fmts(ra):
+                got, hist = pipe.render(fmt=fmt, with_histogram=True)
+                assert np.array_equal(_view(ra, got, fmt), _surface(refc, ra, exp32, fmt)), (h, w, fmt, "surface")
+                assert np.array_equal(hist, exp_hist), (h, w, fmt, "histogram")
+                got = pipe.render(fmt=fmt)
+                assert np.array_equal(_view(ra, got, fmt), _surface(refc, ra, exp32, fmt)), (h, w, fmt, "no histogram")
+            pipe.close()
+
+
+def test_batch_odd_widths(gpu_lib, refc, launch_mode):
+    """rd_batch_create takes odd widths (it answered RD_ERR_UNSUPPORTED through round 5): 131 x 7, one
+    whole tile + the column (129), the overlapped last tile (203, 387), narrower than a tile (5, 1: the masked instance, or no
+    quad at all), row bands, with and without the histogram."""
+    ra = gpu_lib
+    for fmt in _fmts(ra):
+        _batch(ra, refc, 7, 131, 4, fmt)
+        _batch(ra, refc, 9, 129, 3, fmt, bands=2)
+        _batch(ra, refc, 34, 203, 3, fmt, bands=3)
+        _batch(ra, refc, 5, 387, 5, fmt, hist=False)
+        if fmt != ra.FMT_RGB_U8:                                  # (RGB8 narrower than one tile stays with the pipeline's map kernel)
+            _batch(ra, refc, 7, 5, 3, fmt)
+            _batch(ra, refc, 6, 1, 2, fmt)
+    _batch(ra, refc, 1001, 3001, 2, ra.FMT_RGBA_F32)            # more tiles than resident waves
+    _batch(ra, refc, 1001, 3001, 2, ra.FMT_RGB_U8, bands=3)
+
+
+def test_full_size_odd_frame(gpu_lib, refc):
+    """6001 x 4001: every byte of all four surfaces and the exact histogram -- one launch with the
+    histogram, the 8-band host render without, render_full_res_to_bytes, and a multi-frame launch of the batch path."""
+    ra = gpu_lib
+    h, w = 4001, 6001
+    rng = np.random.default_rng([0x52415745, h, w])
+    cfa = random_cfa(rng, h, w)
+    params = random_params(rng)
+    pipe = ra.RenderPipeline.new(7, cfa.reshape(-1), w, h, ra.EditParams(**params), WB_DAYLIGHT, CM_TEST)
+    u = refc.make_uniforms(params, WB_DAYLIGHT, CM_TEST)
+    exp32 = refc.render_f32(cfa, u, nthreads=16)
+    exp_hist = refc.histogram(refc.pack_u8(exp32))
+    for fmt in _fmts(ra):
+        exp = _surface(refc, ra, exp32, fmt)
+        got, hist = pipe.render(fmt=fmt, with_histogram=True)
+        assert np.array_equal(hist, exp_hist), (fmt, "histogram")
+        assert np.array_equal(_view(ra, got, fmt), exp), (fmt, "one launch")
+        got = pipe.render(fmt=fmt)                                 # >= 16 MiB: row bands + chunked read-back
+        assert np.array_equal(_view(ra, got, fmt), exp), (fmt, "row bands")
+        del got, exp
+    assert np.array_equal(pipe.render_full_res_to_bytes().reshape(h, w, 4), refc.pack_u8(exp32))
+    pipe.close()
+    del exp32
+    for fmt in _fmts(ra):
+        _batch(ra, refc, h, w, 2, fmt)
+
+
+def test_export_ring_odd_widths(gpu_lib, refc):
+    ra = gpu_lib
+    for h, w, fmt in ((4001, 6001, ra.FMT_RGB_U8), (7, 131, ra.FMT_RGB_U8), (7, 131, ra.FMT_RGBA_U8), (33, 203, ra.FMT_RGBA_U8), (5, 3, ra.FMT_RGBA_U8)):
+        rng = np.random.default_rng([0x52415745, 4, h, w])
+        cfa = random_cfa(rng, h, w)
+        p = random_params(rng)
+        d = DevBuf.from_array(cfa)
+        u = refc.make_uniforms(p, WB_DAYLIGHT, CM_TEST)
+        exp = refc.pack_u8(refc.render_f32(cfa, u, nthreads=16))[..., :3 if fmt == ra.FMT_RGB_U8 else 4]
+        ex = ra.Exporter(0, w, h, fmt, n_slots=2)
+        fr = ex.frame(d.ptr, ra.EditParams(**p), WB_DAYLIGHT, CM_TEST)
+        s = ex.submit(fr)
+        assert np.array_equal(ex.wait(s), exp), (h, w, fmt, "device-fed")
+        ex.release(s)
+        s = ex.submit_host(cfa, fr)
+        assert np.array_equal(ex.wait(s), exp), (h, w, fmt, "host-fed")
+        ex.release(s)
+        ex.close()
+        d.free()
