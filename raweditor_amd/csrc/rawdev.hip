@@ -520,7 +520,10 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     }
     c.bind();
     if (!record) {
-        (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
+        // (W == 1: no quad, nothing for the export kernel to do -- the column below is the whole frame; a single-frame
+        //  histogram's slab rows, which the export kernel would have overwritten, are cleared instead)
+        if (W >> 1) (void)hipLaunchKernel(c.fn, dim3(blocks), dim3(RD_BLOCK), c.argv, 0, s);
+        else if (HIST && slab32) (void)hipMemsetAsync(slab32, 0, (size_t)blocks * 768u * sizeof(uint32_t), s);
         if (W & 1u) {
             // odd width: the quads above cover columns [0, W - 1); the last column of the band's rows follows on the same
             // stream (rd_develop_lastcol), its histogram counts added to the slab rows just written
@@ -590,7 +593,8 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
     }
     if constexpr (MATH == RD_MATH_PROBE) return;                 // (the probe has burst instances only: rd_probe_launchable)
     else {
-        if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
+        if (!(W >> 1)) { /* one pixel wide: no quad; the column kernel below is the whole frame */ }
+        else if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
         else if (tiles == RD_TILES_OVERLAP) RD_LAUNCH_BATCH(RD_TILES_OVERLAP, false);
         else RD_LAUNCH_BATCH(RD_TILES_MASKED, false);
         if (W & 1u) {                                            // odd width (never a burst launch): the frames' last column, all rows

@@ -181,7 +181,7 @@ static uint64_t rd_frames_per_launch_limit(uint32_t w, uint32_t h, bool hist, ui
 {
     const uint32_t tpu = ((w >> 1) + 63u) / 64u;
     const uint64_t tpf = (uint64_t)(h / 2u + 1u) * tpu;
-    uint64_t kmax = 0xfffffffeull / tpf;
+    uint64_t kmax = tpf ? 0xfffffffeull / tpf : 4096u;           // (a frame ONE pixel wide has no quad, so no tile at all)
     if (hist) { const uint64_t k2 = 0xffffffffull / ((uint64_t)w * h); if (k2 < kmax) kmax = k2; }
     if (kmax > 4096) kmax = 4096;
     if (cap && cap < kmax) kmax = cap;
