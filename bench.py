@@ -1162,17 +1162,19 @@ def extra_export_ring(torch, np, ra, dev, dev_index, cfas, params, n_frames=48):
                      "start in host memory too (48 MB up + 72 MB down per frame)")
     return out
 
-def extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None):
+def extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None, Wr=6000, Hr=4000):
     """A frame width that is not a multiple of the export kernel's 128-pixel tile -- 6000 x 4000, what most 24 MP cameras
     make (the reference renders any size, shaders.rs:181-187) -- beside 6016 x 4016: the same 64-frame batch per surface,
-    the two sizes alternating three times on this box, best of each; `ns_per_px_ratio` = ragged / aligned time per PIXEL."""
-    Wr, Hr = 6000, 4000
+    the two sizes alternating three times on this box, best of each; `ns_per_px_ratio` = ragged / aligned time per PIXEL.
+    Round 6: the same for an ODD width (6001 x 4001: whole quads by the export kernel, the last column by rd_develop_lastcol;
+    rows start on odd 16-bit boundaries, no read burst)."""
     nf = min(64, len(cfas))
     cr, pr = make_batch(torch, np, ra, dev, Wr, Hr, nf, 1 << 21, 1)
     ca, pa = cfas[:nf], params[:nf]
     out = {"config": f"{nf} x {Wr}x{Hr} (W % 128 = {Wr % 128}: every row pair ends in a pulled-back, overlapping tile; RGBA8 / RGB8 rows are "
-                     f"{Wr * 4} / {Wr * 3} bytes, not whole 128-byte lines) beside {nf} x 6016x4016, randomised stacks, fused histogram, "
-                     "strict f32 arithmetic, multi-frame launches"}
+                     f"{Wr * 4} / {Wr * 3} bytes, not whole 128-byte lines" + ("; ODD width: one more launch per multi-frame launch for the last "
+                     "column, 2-byte aligned CFA rows, no read burst for the f32 surface" if Wr % 2 else "") + f") beside {nf} x 6016x4016, "
+                     "randomised stacks, fused histogram, strict f32 arithmetic, multi-frame launches"}
     worst = 0.0
     for fmt_name in ("f32", "f16", "u8", "rgb8"):
         ring = 8 if fmt_name == "f32" else 16
@@ -1221,6 +1223,7 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
                                                  "8 row-band launches per frame (RD_BATCH_PERSISTENT=0), alternating between two streams (RD_BATCH_STREAMS=2)", "per_frame", tiled=True)
     del c5
     out["ragged_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
+    out["odd_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns, Wr=6001, Hr=4001)
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 

@@ -112,6 +112,10 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert rw["verified"] is True and "6000x4000" in rw["config"]
     for k in ("f32", "f16", "u8", "rgb8"):
         assert rw[k]["verified"] is True and 0.8 < rw[k]["ns_per_px_ratio"] < 1.25, (k, rw[k])
+    ow = ex["odd_width"]                                          # round 6: an odd width through the batch path, timed and oracle-checked
+    assert ow["verified"] is True and "6001x4001" in ow["config"] and "ODD" in ow["config"]
+    for k in ("f32", "f16", "u8", "rgb8"):
+        assert ow[k]["verified"] is True and 0.8 < ow[k]["ns_per_px_ratio"] < 1.6, (k, ow[k])
     # the f32 kernel's issue budget (round 5: scalar-base store addresses; parking the slider uniforms measured negative and is off),
     # and the bound as this run's fractions say it
     assert r["roofline"]["valu_issue_cycles_per_tile"] == 1360 and r["roofline"]["bound"] == "hbm"
