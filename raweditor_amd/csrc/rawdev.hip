@@ -504,7 +504,7 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     c.tq_tmax = c.tq_k ? (ndyn + c.tq_k - 1u) / c.tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;   // A/B override: 0 / 1
     // read burst (rd_kernels.h): f32 surface by default; needs 16-byte aligned CFA rows and a launch worth it
-    const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (W % 2u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
+    const bool burst_ok = ((uintptr_t)cfa % 16u) == 0 && (uint64_t)(unit1 - unit0) * W >= (1u << 19);
     const bool burst = burst_ok && FMT == RD_FMT_RGBA_F32 && (burst_env < 0 || burst_env != 0);
     c.blocks = blocks; c.cfa = cfa; c.out = out; c.W = W; c.H = H; c.unit0 = unit0; c.unit1 = unit1; c.tq = tq;
     c.slab32 = slab32; c.slab64 = slab64;
@@ -542,7 +542,7 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
 // (rd_batch_probe_pattern) is built for that instance only.
 static bool rd_burst_launchable(uint32_t W, uint32_t H, bool aligned16)
 {
-    return aligned16 && W >= 128u && (W % 2u) == 0 && (uint64_t)(H / 2u + 1u) * W >= (1u << 19);
+    return aligned16 && W >= 128u && (uint64_t)(H / 2u + 1u) * W >= (1u << 19);      // (any parity: the sweep walks bytes)
 }
 static bool rd_probe_launchable(uint32_t W, uint32_t H, bool aligned16)
 {
@@ -573,6 +573,15 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
 #define RD_LAUNCH_BATCH(TILES, BURST)                                                                                        \
     hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, TILES, MATH, BURST>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes, \
                        W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64, (uint32_t *)nullptr)
+    // odd width: the frames' last column, all rows, behind whichever instance ran (rd_develop_lastcol)
+    auto lastcol = [&]() {
+        if constexpr (MATH != RD_MATH_PROBE) {
+            if (!(W & 1u)) return;
+            const uint64_t need = ((uint64_t)nframes * H + 255u) / 256u;
+            hipLaunchKernelGGL((rd_develop_lastcol<FMT, HIST, MATH>), dim3((uint32_t)(need < blocks ? need : blocks)), dim3(256), 0, s,
+                               (const uint16_t *)nullptr, (void *)nullptr, descs_dev, nframes, W, H, 0u, H, rd_ku{}, (uint32_t *)nullptr, slab64);
+        }
+    };
     if constexpr (FMT == RD_FMT_RGBA_F32 && HIST && MATH == RD_MATH_STRICT) {
         if (stamps && burst) {
 #define RD_LAUNCH_STAMPED(TILES)                                                                                             \
@@ -581,6 +590,7 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
             if (tiles == RD_TILES_WHOLE) RD_LAUNCH_STAMPED(RD_TILES_WHOLE);
             else RD_LAUNCH_STAMPED(RD_TILES_OVERLAP);
 #undef RD_LAUNCH_STAMPED
+            lastcol();
             return;
         }
     }
@@ -588,6 +598,7 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
         if (burst) {
             if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, true);
             else RD_LAUNCH_BATCH(RD_TILES_OVERLAP, true);
+            lastcol();
             return;
         }
     }
@@ -597,11 +608,7 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
         else if (tiles == RD_TILES_WHOLE) RD_LAUNCH_BATCH(RD_TILES_WHOLE, false);
         else if (tiles == RD_TILES_OVERLAP) RD_LAUNCH_BATCH(RD_TILES_OVERLAP, false);
         else RD_LAUNCH_BATCH(RD_TILES_MASKED, false);
-        if (W & 1u) {                                            // odd width (never a burst launch): the frames' last column, all rows
-            const uint64_t need = ((uint64_t)nframes * H + 255u) / 256u;
-            hipLaunchKernelGGL((rd_develop_lastcol<FMT, HIST, MATH>), dim3((uint32_t)(need < blocks ? need : blocks)), dim3(256), 0, s,
-                               (const uint16_t *)nullptr, (void *)nullptr, descs_dev, nframes, W, H, 0u, H, rd_ku{}, (uint32_t *)nullptr, slab64);
-        }
+        lastcol();
     }
 #undef RD_LAUNCH_BATCH
 }

@@ -290,7 +290,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->hist, b->max_frames);
     if ((probe || stamps) && !rd_probe_launchable(b->w, b->h, aligned16))
         return rd_fail(RD_ERR_UNSUPPORTED, "the diagnostic instances exist for the read-burst kernel only: frames at least 128 pixels wide, "
-                                           "even width, 16-byte aligned CFA planes, at least 1 MB of CFA rows");
+                                           "16-byte aligned CFA planes, at least 1 MB of CFA rows");
     const rd_scratch::lease l = b->scratch.get(s, false);
     if (l.idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
     uint32_t *tq = l.tq;

@@ -1431,8 +1431,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             const RD_GLOBAL rd_u4 *src = reinterpret_cast<const RD_GLOBAL rd_u4 *>(reinterpret_cast<const RD_GLOBAL char *>(cfa_b) + b_lo);
             const size_t n16 = ((size_t)row_hi * W * sizeof(uint16_t) - b_lo) / 16u;
             const size_t g0 = (size_t)(blockIdx.x * RD_WAVES + wave) * 64u, gstride = (size_t)nwaves * 64u;
-            // (host guarantees for BURST launches: cfa 16-byte aligned, W even and >= 128, at least 1 MB of CFA rows,
-            //  so src is aligned, n16 >= 64 and every instruction below is unconditional)
+            // (host guarantees for BURST launches: cfa 16-byte aligned, W >= 128, at least 1 MB of CFA rows, so src is aligned,
+            //  n16 >= 64 and every instruction below is unconditional; W may be odd -- the sweep walks bytes)
             {                                                    // launches > 64 MB only: the part beyond 8 x 1 KiB per wave
                 uint32_t sink = 0;
                 for (size_t i0 = g0 + 8u * gstride; i0 + 64u <= n16; i0 += gstride) {
