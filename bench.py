@@ -488,7 +488,7 @@ def _median(xs):
     return 0.0 if not n else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
 
 
-def launch_summary(timeline, alg_bytes_per_launch=None):
+def launch_summary(timeline, alg_bytes_per_launch=None, with_note=False):
     """[(call, start_us, end_us), ...] of rd_batch_launch_timeline -> what the launches of a step cost, by position in
     the step (a step = one develop call; the median over the kept calls), and what lies between them."""
     calls = {}
@@ -510,17 +510,20 @@ def launch_summary(timeline, alg_bytes_per_launch=None):
            "kernel_ms_per_step": round(sum(by_pos) / 1e3, 4),
            "gap_us_between_launches": {"median": round(_median(inner), 2), "max": round(max(inner), 2)} if inner else None,
            "step_boundary_gap_us": {"median": round(_median(boundary), 1), "max": round(max(boundary), 1)} if boundary else None,
-           "instrumented_ms_per_step": round(_median(period) / 1e3, 4) if period else None,
-           "note": "an untimed pass AFTER the timed region with a HIP event pair around every fused launch (rd_batch_set_launch_timing): "
-                   "launch_us_by_position = median over the steps of each launch's own duration; step_boundary_gap_us = last launch of a "
-                   "step -> first launch of the next (histogram fold, all-reduce when N > 1, descriptor upload and the event packets); "
-                   "the pairs put two barrier packets between launches, so instrumented_ms_per_step is not the timed region's figure"}
+           "instrumented_ms_per_step": round(_median(period) / 1e3, 4) if period else None}
+    if with_note:
+        out["note"] = ("an untimed pass AFTER the timed region with a HIP event pair around every fused launch (rd_batch_set_launch_timing): "
+                       "launch_us_by_position = median over the steps of each launch's own duration; step_boundary_gap_us = last launch of a "
+                       "step -> first launch of the next (histogram fold, all-reduce when N > 1, descriptor upload and the event packets).  A "
+                       "pair's duration includes the command processor's handling of its two marker packets (about gap_us_between_launches), "
+                       "which an un-instrumented stream hides under the previous launch: kernel_ms_per_step can therefore exceed ms_per_step "
+                       "by ~1 % (a NEGATIVE gap_ms_per_step means: no idle time between launches worth the name)")
     if alg_bytes_per_launch:
         out["GBps_median_launch"] = round(alg_bytes_per_launch / (_median(durs) * 1e-6) / 1e9, 1)
     return out
 
 
-def instrumented_pass(be, step_fn, sync_fn, n_steps, alg_bytes_per_launch=None):
+def instrumented_pass(be, step_fn, sync_fn, n_steps, alg_bytes_per_launch=None, with_note=False):
     """n_steps of the caller's step with an event pair around every launch; None when the library refuses."""
     try:
         be.set_launch_timing(n_steps)
@@ -529,7 +532,7 @@ def instrumented_pass(be, step_fn, sync_fn, n_steps, alg_bytes_per_launch=None):
         sync_fn()
         tl = be.launch_timeline()
         be.set_launch_timing(0)
-        return launch_summary(tl, alg_bytes_per_launch)
+        return launch_summary(tl, alg_bytes_per_launch, with_note)
     except Exception as e:  # noqa: BLE001  (a diagnosis must not cost the line)
         try:
             be.set_launch_timing(0)
@@ -883,6 +886,13 @@ def result_line(args, world, F, W, H, elapsed, dev_ms, lpc, ring_len, verified, 
             "box_pattern_GBps": pattern_GBps,
             "frac_of_box_pattern": round(achieved / pattern_GBps, 4) if pattern_GBps else None,
             "box_pattern": pattern if pattern is not None else diag.get("pattern"),
+            # (copies of the line's top-level diagnosis keys: a record that keeps `roofline` whole keeps them too)
+            "kernel_ms_per_step": kernel_ms, "gap_ms_per_step": round(ms_per_step - kernel_ms, 4) if kernel_ms else None,
+            "clock_under_kernel_GHz": (diag.get("clock_under_kernel") or {}).get("GHz_median"),
+            "clocks": {k: (v.get("median") if isinstance(v, dict) else v) for k, v in (diag.get("clocks") or {}).items()
+                       if k in ("sclk_MHz", "mclk_MHz", "power_W", "temp_hotspot_C", "temp_mem_C", "gfx_activity_pct", "samples", "source")} or None,
+            "clocks_reason": diag.get("clocks_reason"),
+            "descriptor_upload_cost_ms_per_step": (diag.get("descriptor_upload_ab") or {}).get("upload_cost_ms_per_step"),
         },
     }
 
@@ -1346,7 +1356,7 @@ def run_ranks(args):
         alg_launch = BYTES_PER_PX[args.format] * W * H * F / lpc
         with torch.cuda.stream(stream), quiet_gc():
             # (a) an event pair around every fused launch, six steps
-            diag["launches"] = instrumented_pass(be, step, barrier, 6, alg_launch)
+            diag["launches"] = instrumented_pass(be, step, barrier, 6, alg_launch, with_note=True)
             # (b) the shader clock UNDER the kernel: two ordinary steps through the instance that stamps its clocks
             try:
                 got_clock = []
@@ -1547,6 +1557,26 @@ def run_ranks(args):
             result["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, H, args.cpu_seconds)
+    if rank == 0 and not args.no_diagnose:
+        # LAST key of the line (a record that keeps only the tail of stdout keeps this): the self-diagnosis in one screenful
+        rf, ex = result["roofline"], result.get("extra_configs") or {}
+        la = rf.get("launches") or {}
+        u8 = ex.get("batch_rgba8") if isinstance(ex.get("batch_rgba8"), dict) else {}
+        result["diagnosis"] = {
+            "value_MPps": result["value"], "frac": rf["frac"], "frac_kernel": rf.get("frac_kernel"), "frac_of_box_pattern": rf.get("frac_of_box_pattern"),
+            "ms_per_step": result["ms_per_step"], "kernel_ms_per_step": result.get("kernel_ms_per_step"), "gap_ms_per_step": result.get("gap_ms_per_step"),
+            "launch_us": la.get("launch_us"), "launch_us_by_position": la.get("launch_us_by_position"),
+            "gap_us_between_launches": la.get("gap_us_between_launches"), "step_boundary_gap_us": la.get("step_boundary_gap_us"),
+            "clock_under_kernel_GHz": rf.get("clock_under_kernel_GHz"), "clocks": rf.get("clocks"), "clocks_reason": rf.get("clocks_reason"),
+            "box_before": {k: (rf.get("box_before") or {}).get(k) for k in ("copy", "fill", "read", "valu_effective_GHz")},
+            "box_after": {k: (rf.get("box_after") or {}).get(k) for k in ("copy", "fill", "read", "valu_effective_GHz")},
+            "box_pattern_GBps": rf.get("box_pattern_GBps"), "box_pattern_launch_us": ((rf.get("box_pattern") or {}).get("launch_us") or {}).get("median"),
+            "descriptor_upload_ab_ms_per_step": {k: (result.get("descriptor_upload_ab") or {}).get(k) for k in ("rotating_ms_per_step", "static_ms_per_step")},
+            "batch_rgba8": {"us_per_frame": u8.get("us_per_frame"), "frac": (u8.get("roofline") or {}).get("frac"),
+                            "launch_us": (u8.get("launches") or {}).get("launch_us"), "kernel_ms_per_step": u8.get("kernel_ms_per_step"),
+                            "gap_ms_per_step": u8.get("gap_ms_per_step"), "ms_per_step": u8.get("ms")},
+            "cpu_baseline_MPps": (result.get("cpu_baseline") or {}).get("value"),
+        }
     failed = False
     if rank == 0:
         if result.get("invalid"):                          # not a measurement of N GPUs: stderr + non-zero exit, no stdout line

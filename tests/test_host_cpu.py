@@ -133,7 +133,8 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.rd_update_uniforms(None, None) == -1
     out = C.c_void_p()
     assert L.rd_batch_create(0, 0, 10, 0, 1, C.byref(out)) == -1          # empty frame
-    assert L.rd_batch_create(0, 7, 10, 0, 1, C.byref(out)) == -5          # odd width unsupported in batch
+    assert L.rd_batch_create(0, 7, 10, 0, 1, C.byref(out)) == -2          # an odd width is no longer refused (round 6): the call gets as far as the missing device
+    assert L.rd_batch_create(0, 126, 10, 3, 1, C.byref(out)) == -5        # RGB8 narrower than one tile: still the pipeline's map kernel only
     L.rd_pipeline_destroy(None)                                             # NULL is a no-op
     L.rd_batch_destroy(None)
     with pytest.raises(ra.RawdevError):
