@@ -484,3 +484,14 @@ def test_f16_threshold_tables_construction_against_the_oracle(refc):
     assert h0[0] == 0 and s0[0] == 0
     od, _ = oracle(np.array([dip - 1, dip, dip + 1], np.int64))
     assert od[1] < od[0] and od[2] == od[0]
+
+
+def test_graft_entry_build_is_in_step_with_the_abi():
+    """The driver runs __graft_entry__.build() every round: it must pass on the tree as it stands (round 6 bumped the ABI to 5
+    and the entry still asserted 4 -- caught on the GPU box, not here; this test is why it cannot happen again)."""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
