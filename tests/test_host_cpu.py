@@ -490,6 +490,7 @@ def test_graft_entry_build_is_in_step_with_the_abi():
     """The driver runs __graft_entry__.build() every round: it must pass on the tree as it stands (round 6 bumped the ABI to 5
     and the entry still asserted 4 -- caught on the GPU box, not here; this test is why it cannot happen again)."""
     import importlib
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
