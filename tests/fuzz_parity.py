@@ -131,7 +131,10 @@ def check_batch(rng):
     accumulated histogram against the oracle.  Returns (mismatch descriptions, frames)."""
     from raweditor_amd._lib import RdFrame
     from tests.gpu_util import DevBuf, sync
-    w = int(2 * rng.integers(1, 200)) if rng.random() < 0.6 else int(128 * rng.integers(1, 9))   # batch: even widths
+    # batch: any width since round 6 -- even ones around the tile, multiples of the tile, and odd ones (whole quads by the export
+    # kernel + rd_develop_lastcol; 1 = no quad at all)
+    sel = rng.random()
+    w = int(2 * rng.integers(1, 200)) if sel < 0.45 else int(128 * rng.integers(1, 9)) if sel < 0.7 else int(2 * rng.integers(0, 200) + 1)
     h = int(rng.integers(1, 60))
     n = int(rng.integers(1, 13))
     math = int(rng.integers(0, 2))
