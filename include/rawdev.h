@@ -44,8 +44,9 @@ extern "C" {
  * one worker thread per device for the life of the handle instead of starting N threads per call; new entry points
  * rd_node_batch_histogram_enqueue / _fetch (the global histogram without draining the devices).
  * 5: no signature changed.  rd_node_batch_histogram_fetch returns the SUM of every interval enqueued since the last fetch
- * (ABI 4 returned the last one and dropped the others); new measurement aids rd_batch_set_launch_timing,
- * rd_batch_launch_timeline, rd_batch_probe_pattern, rd_batch_measure_clock. */
+ * (ABI 4 returned the last one and dropped the others); rd_batch_create / rd_exporter_create take odd widths (ABI 4:
+ * RD_ERR_UNSUPPORTED) and the pipeline renders them with the export kernel too; new measurement aids
+ * rd_batch_set_launch_timing, rd_batch_launch_timeline, rd_batch_probe_pattern, rd_batch_measure_clock. */
 #define RD_ABI_VERSION 5
 
 typedef enum rd_status {
@@ -220,8 +221,10 @@ typedef struct rd_frame {
 
 /* A batch context owns the histogram slab for frames of one size/format on one device.  Use one context per
  * stream and per thread (the accumulator is private to the context; calls on one context are not re-entrant).
- * Frame sizes: any height; the width must be even (RD_ERR_UNSUPPORTED otherwise: rd_render serves odd widths), and
- * for RD_FMT_RGB_U8 at least 128.  Every even width from 128 up runs at the full rate, a multiple of 128 or not. */
+ * Frame sizes: any height, any width (ABI 5: an odd width is taken too -- the export kernel develops the whole 2 x 2 blocks of
+ * a row pair and a small second kernel the last column; through ABI 4 it was RD_ERR_UNSUPPORTED); for RD_FMT_RGB_U8 at least
+ * 128 pixels.  Every even width from 128 up runs at the full rate, a multiple of 128 or not; an odd width costs 5-8 % on
+ * the narrow surfaces and 17-27 % on RGBA-f32, whose 16-byte pixels put every other row half a 32-byte sector off. */
 int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format,
                     uint32_t with_histogram, rd_batch **out);
 void rd_batch_destroy(rd_batch *b);

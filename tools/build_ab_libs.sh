@@ -7,10 +7,17 @@
 #                                                   uniforms stay in SGPRs, no waves-per-SIMD target for the compiler
 #   tools/librawdev_r5nopark.so    -DRD_F32_PARK=0  the waves-per-SIMD attribute alone (= the product since the A/B)
 #   tools/librawdev_r5park.so      -DRD_F32_PARK=1  six slider uniforms of the f32 multi-frame kernel parked in VGPRs (dropped)
-# `bash tools/build_ab_libs.sh r5` builds only the round-5 pair.
+#   tools/librawdev_r6rgbplain.so  -DRD_RGB8_ST_PLAIN  RGB8 surface stored with write-back instead of non-temporal stores (dropped:
+#                                                   profiles/r06_rgb8_ragged_ab.txt)
+# `bash tools/build_ab_libs.sh r5` builds only the round-5 pair, `... r6` only the round-6 build.
 set -eu
 cd "$(dirname "$0")/.."
 FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -Wall -Wextra -pthread -ldl"
+if [ "${1:-all}" = r6 ]; then
+  /opt/rocm/bin/hipcc $FLAGS -DRD_RGB8_ST_PLAIN -o tools/librawdev_r6rgbplain.so raweditor_amd/csrc/rawdev.hip
+  ls -la tools/librawdev_r6*.so
+  exit 0
+fi
 if [ "${1:-all}" != r5 ]; then
   /opt/rocm/bin/hipcc $FLAGS -DRD_Q8_LUT=0 -o tools/librawdev_r4nolut.so raweditor_amd/csrc/rawdev.hip
   /opt/rocm/bin/hipcc $FLAGS -DRD_F16_LUT=0 -o tools/librawdev_r4nof16lut.so raweditor_amd/csrc/rawdev.hip
