@@ -1579,6 +1579,22 @@ def run_ranks(args):
             "batch_rgba8": {"us_per_frame": u8.get("us_per_frame"), "frac": (u8.get("roofline") or {}).get("frac"),
                             "launch_us": (u8.get("launches") or {}).get("launch_us"), "kernel_ms_per_step": u8.get("kernel_ms_per_step"),
                             "gap_ms_per_step": u8.get("gap_ms_per_step"), "ms_per_step": u8.get("ms")},
+            # the other configurations in one line each (their full objects are further up, in extra_configs)
+            "extras": {
+                "config5_shape_f16": {k: (ex.get("config5_shape_f16") or {}).get(k) for k in ("us_per_frame", "MP_per_s", "launches_per_step")}
+                                     | {"frac": ((ex.get("config5_shape_f16") or {}).get("roofline") or {}).get("frac")},
+                "config5_shape_f16_tiled": {k: (ex.get("config5_shape_f16_tiled") or {}).get(k) for k in ("us_per_frame", "MP_per_s", "launches_per_step")}
+                                           | {"frac": ((ex.get("config5_shape_f16_tiled") or {}).get("roofline") or {}).get("frac")},
+                "single_frame_f32_ms": (ex.get("single_frame_f32") or {}).get("ms"),
+                "full_res_to_bytes_pinned_ms": ((ex.get("full_res_to_bytes") or {}).get("pinned_dst") or {}).get("ms"),
+                "pcie_floor_ms": (ex.get("full_res_to_bytes") or {}).get("pcie_floor_ms"),
+                "export_ring_ms_per_frame": {k: ((ex.get("export_ring") or {}).get(k) or {}).get("ms_per_frame") for k in ("rgb8", "rgba8")},
+                "ragged_width_ns_per_px_ratio": {k: ((ex.get("ragged_width") or {}).get(k) or {}).get("ns_per_px_ratio") for k in ("f32", "f16", "u8", "rgb8")},
+                "odd_width_ns_per_px_ratio": {k: ((ex.get("odd_width") or {}).get(k) or {}).get("ns_per_px_ratio") for k in ("f32", "f16", "u8", "rgb8")},
+                "all_verified": all(bool((ex.get(k) or {}).get("verified")) for k in ("single_frame_f32", "full_res_to_bytes", "batch_rgba8", "config5_shape_f16",
+                                                                                   "config5_shape_f16_tiled", "ragged_width", "odd_width")) if ex and "error" not in ex else None,
+            },
+            "verified": result.get("verified"),
             "cpu_baseline_MPps": (result.get("cpu_baseline") or {}).get("value"),
         }
     failed = False

@@ -143,6 +143,15 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert ab["rotating_ms_per_step"] > 0 and ab["static_ms_per_step"] > 0 and len(ab["rotating_all"]) == 3
     assert ex["batch_rgba8"]["launches"]["launch_us"]["median"] > 0 and ex["batch_rgba8"]["kernel_ms_per_step"] > 0
     assert ex["config5_shape_f16"]["launches"]["launches_per_step"] == ex["config5_shape_f16"]["launches_per_step"]
+    # ... and says it where a record that keeps `roofline` whole, or only the tail of stdout, still has it
+    assert list(r.keys())[-1] == "diagnosis"
+    dg = r["diagnosis"]
+    assert dg["value_MPps"] == r["value"] and dg["frac"] == rf["frac"] and dg["kernel_ms_per_step"] == r["kernel_ms_per_step"]
+    assert len(dg["launch_us_by_position"]) == 2 and dg["clock_under_kernel_GHz"] == ck["GHz_median"] and dg["box_pattern_GBps"] == rf["box_pattern_GBps"]
+    assert dg["extras"]["all_verified"] is True and dg["extras"]["config5_shape_f16"]["frac"] == ex["config5_shape_f16"]["roofline"]["frac"]
+    assert dg["batch_rgba8"]["us_per_frame"] == ex["batch_rgba8"]["us_per_frame"] and dg["verified"] is True
+    assert rf["kernel_ms_per_step"] == r["kernel_ms_per_step"] and rf["clock_under_kernel_GHz"] == ck["GHz_median"]
+    assert len(json.dumps(dg)) < 6000                              # fits the tail a driver keeps
     q = _bench(["--frames", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-diagnose"], {})
     assert q["verified"] is True and q["kernel_ms_per_step"] is None and q["roofline"]["launches"] is None and q["clocks"] is None
 
