@@ -475,11 +475,21 @@ struct rd_quads_call {
 
 // How the export kernel tiles a row of W pixels (W even; rd_kernels.h, TILES).  RD_TILES=overlap (A/B switch) runs the
 // pulled-back-last-tile instance on widths that need none.
-static int rd_tiles_mode(uint32_t W)
+static int rd_tiles_mode(uint32_t W, uint32_t fmt)
 {
     static const bool force_overlap = getenv("RD_TILES") && !strcmp(getenv("RD_TILES"), "overlap");
+    static const bool no_shift = getenv("RD_TILES") && !strcmp(getenv("RD_TILES"), "noshift");   // A/B: such f32 frames through OVERLAP
     if (W < 128u) return RD_TILES_MASKED;
+    // f32 rows that do not start on 64-byte boundaries (W % 4 != 0; no camera makes one, a crop can): shifted store windows
+    if ((W & 3u) && fmt == RD_FMT_RGBA_F32 && !no_shift) return RD_TILES_SHIFT;
     return (W % 128u == 0 && !force_overlap) ? RD_TILES_WHOLE : RD_TILES_OVERLAP;
+}
+
+// Tiles per unit (row pair): 64-quad tiles that abut or whose last one is pulled back; RD_TILES_SHIFT's tiles own 62 quads.
+static uint32_t rd_tiles_per_unit(uint32_t W, uint32_t fmt)
+{
+    const uint32_t qpr = W >> 1;
+    return rd_tiles_mode(W, fmt) == RD_TILES_SHIFT ? (qpr + 61u) / 62u : (qpr + 63u) / 64u;
 }
 
 template <int FMT, bool HIST, int MATH>
@@ -492,7 +502,7 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     rd_quads_call &c = record ? *record : local;
     c.u = u_in;
     if (no_elide) c.u.elide = 0u;
-    const uint32_t tpu = ((W >> 1) + 63u) / 64u;           // 64-quad tiles per unit
+    const uint32_t tpu = rd_tiles_per_unit(W, FMT);        // 64-quad tiles per unit
     c.tpu = tpu;
     c.tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;   // rd_kernels.h: split()
     const uint32_t nwaves = blocks * RD_WAVES;
@@ -510,11 +520,13 @@ static void rd_launch_quads_t(const uint16_t *cfa, void *out, uint32_t W, uint32
     c.slab32 = slab32; c.slab64 = slab64;
     // whole tiles for every even width from 128 up: a width that is not a multiple of 128 overlaps its last tile
     // (rd_kernels.h, TILES); the masked instance is left for frames narrower than one tile
-    const int tiles = rd_tiles_mode(W);
+    const int tiles = rd_tiles_mode(W, FMT);
     c.fn = tiles == RD_TILES_WHOLE ? (const void *)rd_develop_quads<FMT, HIST, RD_TILES_WHOLE, MATH, false>
          : tiles == RD_TILES_OVERLAP ? (const void *)rd_develop_quads<FMT, HIST, RD_TILES_OVERLAP, MATH, false>
                                      : (const void *)rd_develop_quads<FMT, HIST, RD_TILES_MASKED, MATH, false>;
-    if constexpr (FMT == RD_FMT_RGBA_F32) {     // the burst variant exists for the f32 surface only
+    if constexpr (FMT == RD_FMT_RGBA_F32) {     // the burst variant and the odd-width tiling exist for the f32 surface only
+        if (tiles == RD_TILES_SHIFT) c.fn = burst ? (const void *)rd_develop_quads<FMT, HIST, RD_TILES_SHIFT, MATH, true>
+                                                  : (const void *)rd_develop_quads<FMT, HIST, RD_TILES_SHIFT, MATH, false>;
         if (burst && tiles == RD_TILES_WHOLE) c.fn = (const void *)rd_develop_quads<FMT, HIST, RD_TILES_WHOLE, MATH, true>;
         if (burst && tiles == RD_TILES_OVERLAP) c.fn = (const void *)rd_develop_quads<FMT, HIST, RD_TILES_OVERLAP, MATH, true>;
     }
@@ -547,7 +559,7 @@ static bool rd_burst_launchable(uint32_t W, uint32_t H, bool aligned16)
 static bool rd_probe_launchable(uint32_t W, uint32_t H, bool aligned16)
 {
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;
-    return rd_burst_launchable(W, H, aligned16) && burst_env != 0;
+    return rd_burst_launchable(W, H, aligned16) && (W % 4u) == 0 && burst_env != 0;      // (the diagnostic instances: no shifted windows)
 }
 
 // Multi-frame launch (rd_develop_batch): descs_dev[0 .. nframes-1] are whole frames of W x H.
@@ -557,7 +569,7 @@ template <int FMT, bool HIST, int MATH>
 static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, uint32_t W, uint32_t H, uint32_t blocks,
                               bool burst_ok, unsigned long long *slab64, uint32_t *tq, hipStream_t s, uint32_t *stamps = nullptr)
 {
-    const uint32_t tpu = ((W >> 1) + 63u) / 64u;
+    const uint32_t tpu = rd_tiles_per_unit(W, FMT);
     const uint32_t tpu_magic = tpu > 1u ? (uint32_t)((1ull << 32) / tpu) : 0xffffffffu;
     const uint32_t tpf = (H / 2u + 1u) * tpu;               // tiles per frame
     const uint32_t tpf_magic = tpf > 1u ? (uint32_t)((1ull << 32) / tpf) : 0xffffffffu;
@@ -569,7 +581,7 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
     const uint32_t tq_tmax = tq_k ? (ndyn + tq_k - 1u) / tq_k : 0u;
     static const int burst_env = getenv("RD_BURST") ? atoi(getenv("RD_BURST")) : -1;
     const bool burst = FMT == RD_FMT_RGBA_F32 && rd_burst_launchable(W, H, burst_ok) && (burst_env < 0 || burst_env != 0);
-    const int tiles = rd_tiles_mode(W);
+    const int tiles = rd_tiles_mode(W, FMT);
 #define RD_LAUNCH_BATCH(TILES, BURST)                                                                                        \
     hipLaunchKernelGGL((rd_develop_batch<FMT, HIST, TILES, MATH, BURST>), dim3(blocks), dim3(RD_BLOCK), 0, s, descs_dev, nframes, \
                        W, H, tpu, tpu_magic, tpf, tpf_magic, tq_k, tq_tmax, tq, slab64, (uint32_t *)nullptr)
@@ -590,6 +602,14 @@ static void rd_launch_batch_t(const rd_frame_desc *descs_dev, uint32_t nframes, 
             if (tiles == RD_TILES_WHOLE) RD_LAUNCH_STAMPED(RD_TILES_WHOLE);
             else RD_LAUNCH_STAMPED(RD_TILES_OVERLAP);
 #undef RD_LAUNCH_STAMPED
+            lastcol();
+            return;
+        }
+    }
+    if constexpr (FMT == RD_FMT_RGBA_F32 && MATH != RD_MATH_PROBE) {
+        if (tiles == RD_TILES_SHIFT) {                           // W % 4 != 0: 64-byte-aligned store windows (rd_kernels.h)
+            if (burst) RD_LAUNCH_BATCH(RD_TILES_SHIFT, true);
+            else RD_LAUNCH_BATCH(RD_TILES_SHIFT, false);
             lastcol();
             return;
         }
@@ -665,7 +685,7 @@ static int rd_enqueue_render(const rd_launch_cfg &cfg, const uint16_t *cfa, uint
                                                  // below must be THIS launch's, not an earlier failed call's
     if (use_quads) {
         if (!tq) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
-        const uint64_t items = (uint64_t)(unit1 - unit0) * (((W >> 1) + 63u) / 64u) * 64u;   // lanes
+        const uint64_t items = (uint64_t)(unit1 - unit0) * rd_tiles_per_unit(W, fmt) * 64u;   // lanes
         if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame too large for 32-bit item index");
         blocks = fixed_blocks ? fixed_blocks : rd_blocks_for(cfg, items, hist);
         RD_DISPATCH(rd_launch_quads_t, fmt, hist, math, cfa, out, W, H, unit0, unit1, blocks, u, slab32, slab64, tq, s, record);

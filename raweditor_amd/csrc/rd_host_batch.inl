@@ -90,7 +90,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     if (!w || !h) return rd_fail(RD_ERR_INVALID_ARG, "empty frame %ux%u", w, h);
     if (!rd_format_bytes_per_pixel(fmt)) return rd_fail(RD_ERR_INVALID_ARG, "unknown format %u", fmt);
     if (fmt == RD_FMT_RGB_U8 && w < 128u) return rd_fail(RD_ERR_UNSUPPORTED, "RGB8 batch export needs a frame at least 128 pixels wide (got %u)", w);
-    const uint64_t items = (uint64_t)(h / 2u + 1u) * (((w >> 1) + 63u) / 64u) * 64u;
+    const uint64_t items = (uint64_t)(h / 2u + 1u) * rd_tiles_per_unit(w, fmt) * 64u;
     if (items >= 0xffffffffull) return rd_fail(RD_ERR_UNSUPPORTED, "frame %ux%u too large", w, h);
     int n_cu = 0;
     int rc = rd_check_device(device, &n_cu);
@@ -177,9 +177,9 @@ RD_CATCH_INT(rd_batch_set_math_mode)
 // How many frames one multi-frame launch may hold for frames of w x h: the 32-bit tile index, the u32 histogram bins a
 // workgroup keeps in LDS for the whole launch (every pixel of the launch could, in principle, land in one bin of one
 // workgroup), and the per-format default / RD_BATCH_MAX_FRAMES cap.
-static uint64_t rd_frames_per_launch_limit(uint32_t w, uint32_t h, bool hist, uint32_t cap)
+static uint64_t rd_frames_per_launch_limit(uint32_t w, uint32_t h, uint32_t fmt, bool hist, uint32_t cap)
 {
-    const uint32_t tpu = ((w >> 1) + 63u) / 64u;
+    const uint32_t tpu = rd_tiles_per_unit(w, fmt);
     const uint64_t tpf = (uint64_t)(h / 2u + 1u) * tpu;
     uint64_t kmax = tpf ? 0xfffffffeull / tpf : 4096u;           // (a frame ONE pixel wide has no quad, so no tile at all)
     if (hist) { const uint64_t k2 = 0xffffffffull / ((uint64_t)w * h); if (k2 < kmax) kmax = k2; }
@@ -215,7 +215,7 @@ extern "C" int rd_batch_plan_launches(uint32_t width, uint32_t height, uint32_t 
     const size_t bpp = rd_format_bytes_per_pixel(format);
     if (!width || !height || !bpp || (!frames && n_frames)) return rd_fail(RD_ERR_INVALID_ARG, "rd_batch_plan_launches: bad argument");
     const uint32_t cap = max_frames ? max_frames : (format == RD_FMT_RGBA_F32 ? 8u : 32u);
-    const uint64_t kmax = rd_frames_per_launch_limit(width, height, with_histogram != 0, cap);
+    const uint64_t kmax = rd_frames_per_launch_limit(width, height, format, with_histogram != 0, cap);
     const size_t surf = (size_t)width * height * bpp;
     int launches = 0;
     for (size_t i0 = 0; i0 < n_frames;) {
@@ -287,7 +287,7 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     b->db_last = j;
     const rd_frame_desc *descs = b->db[j].dev;
 
-    const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->hist, b->max_frames);
+    const uint64_t kmax = rd_frames_per_launch_limit(b->w, b->h, b->fmt, b->hist, b->max_frames);
     if ((probe || stamps) && !rd_probe_launchable(b->w, b->h, aligned16))
         return rd_fail(RD_ERR_UNSUPPORTED, "the diagnostic instances exist for the read-burst kernel only: frames at least 128 pixels wide, "
                                            "16-byte aligned CFA planes, at least 1 MB of CFA rows");

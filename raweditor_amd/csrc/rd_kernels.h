@@ -848,9 +848,22 @@ __device__ __forceinline__ void rd_store_px(void *out, size_t px, const rd_rgb &
 // One tile's results, packed the way its surface stores want them, carried in registers from the
 // iteration that computes them to the next one, which stores them (f16 / u8 / rgb8; the f32 tile waits
 // in the LDS stage).
+//   RD_TILES_SHIFT    the f32 surface at a width that is not a multiple of 4, W >= 128 (round 6).  Its rows are 16 W bytes, so
+//                     they start 16, 32 or 48 bytes into a 64-byte block, and with tiles cut at pixel 128 k every 1-KiB store
+//                     begins and ends inside a block that another wave completes at another time.  Measured, time per pixel
+//                     against 6016: 6008 px (rows on 128-byte lines) x1.03, 6004 (64-byte blocks) x1.04, 6002 (32 bytes) x1.16,
+//                     6001 x1.21-1.27 -- the memory system wants whole 64-byte blocks (aligning to 32-byte sectors alone, tried
+//                     first, changed nothing).  Here a tile OWNS 62 quads and every wave still develops 64: tile k's window is the
+//                     quads [62 k, 62 k + 64), and in row r it stores the pixels [124 k + s_r, 124 (k + 1) + s_r), where
+//                     s_r = (-r W) mod 4 is the shift that puts row r's stores on 64-byte boundaries -- different for the two rows
+//                     of the pair, at most 3, which is what the two spare quads are for.  Tile 0 starts every row at pixel 0, the
+//                     last tile is pulled back to end at the row's last quad (like OVERLAP) and stores up to it.  A quad is
+//                     counted in the histogram by the tile that owns it; an odd width's last column stays rd_develop_lastcol's.
+//                     3 % more tiles, on a kernel that waits for memory.
 #define RD_TILES_MASKED 0
 #define RD_TILES_WHOLE 1
 #define RD_TILES_OVERLAP 2
+#define RD_TILES_SHIFT 3
 template <int FMT> struct rd_tile_out;
 template <> struct rd_tile_out<RD_FMT_RGBA_F32> { };      // nothing: the f32 tile waits in the wave's LDS stage, not in registers
 template <> struct rd_tile_out<RD_FMT_RGBA_F16> { uint32_t a0, a1, b0, b1, c0, c1; };   // half2 pairs: rg, b1
@@ -897,6 +910,8 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     // (raweditor_amd/kernel_resources.json; the build fails beyond the budget).  (An SGPR source also halves the issue rate of v_mul/v_add/v_fma_f32, tools/valu_probe2.hip, but
     // that is not what limits this kernel: DESIGN.md section 6.)
     constexpr bool FULL = TILES != RD_TILES_MASKED;
+    constexpr bool SHIFT = TILES == RD_TILES_SHIFT;
+    static_assert(!SHIFT || FMT == RD_FMT_RGBA_F32, "RD_TILES_SHIFT is the f32 surface's instance");
     rd_ku u;
     auto adopt = [&](const rd_ku &src_mem) {                     // take over one frame's uniforms (MULTI: on every frame change)
         rd_ku src = src_mem;
@@ -997,6 +1012,10 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
     // first quad of tile pq of a unit (wave-uniform, SALU): tiles abut, except that RD_TILES_OVERLAP pulls the last one back
     // to end at the row's end
     auto qbase = [&](uint32_t pq) -> uint32_t {
+        if constexpr (SHIFT) {                                   // the 64-quad window of tile pq starts at its own 62 quads
+            const uint32_t b = pq * 62u, last = qpr - 64u;
+            return b < last ? b : last;
+        }
         const uint32_t b = pq * 64u;
         if constexpr (TILES == RD_TILES_OVERLAP) { const uint32_t last = qpr - 64u; return b < last ? b : last; }
         else return b;
@@ -1090,7 +1109,10 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         const bool has_a = tu != 0u, has_b = 2u * tu < H;        // wave-uniform
         // lanes that count in the histogram: all (WHOLE); all but the quads a pulled-back last tile shares with its
         // predecessor (OVERLAP: tq * 64 - qbase(tq) of them, 0 for every other tile); the lanes inside the row (MASKED)
-        const bool valid = TILES == RD_TILES_WHOLE || (TILES == RD_TILES_OVERLAP ? lane >= tq * 64u - qbase(tq) : (tq * 64u + lane) < qpr);
+        // (SHIFT: the quads [62 tq, 62 tq + 62) are this tile's own -- the last tile's reach the row's end; the rest of the window is a neighbour's)
+        const bool valid = TILES == RD_TILES_WHOLE ||
+                           (SHIFT ? (qbase(tq) + lane >= tq * 62u && qbase(tq) + lane < tq * 62u + 62u)
+                                  : TILES == RD_TILES_OVERLAP ? lane >= tq * 64u - qbase(tq) : (tq * 64u + lane) < qpr);
         float A, B, C, D;
 #ifdef RD_BUDGET_ELIDE                                           // tools/isa_budget.py: one path in the assembly
         constexpr bool black0 = true;
@@ -1309,7 +1331,38 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
         const size_t row_a_px = has_a ? (size_t)(2u * tu - 1u) * W : row_b_px;
         const uint32_t q0 = qbase(tq);                           // the tile's first quad
         const bool valid = FULL || q0 + lane < qpr;
-        if constexpr (FMT == RD_FMT_RGBA_F32) {
+        if constexpr (SHIFT) {
+            // 64-byte-aligned store windows (see RD_TILES_SHIFT above): in window-relative pixels row a stores [ra0, ra0 + na) and
+            // row b [rb0, rb0 + nb); a lane past the end of its window repeats the window's last pixel (same address, same
+            // data), so the four stores stay unconditional.
+            (void)r; (void)valid;
+            const rd_f4 *st = stage + (size_t)wave * 192u;
+            __builtin_amdgcn_wave_barrier();
+            RD_GLOBAL rd_f4 *o = reinterpret_cast<RD_GLOBAL rd_f4 *>(out);
+            const bool last = tq + 1u == tpu;
+            const uint32_t row_a = has_a ? 2u * tu - 1u : 2u * tu, row_b = has_b ? 2u * tu : 2u * tu - 1u;    // absolute rows, as row_*_px
+            const uint32_t sa = (0u - row_a * W) & 3u, sb = (0u - row_b * W) & 3u;                             // the rows' shifts
+            const uint32_t nat = 124u * tq - 2u * q0;            // where pixel 124 tq lies in the window (0, or more in the pulled-back last tile)
+            // (a window never leaves the tile's 128 pixels: next to a last tile that owns a single quad the window before it is
+            //  pulled back too, and a shift of 3 would push its end -- or the last tile's start -- past them; a window that comes out
+            //  empty re-stores its tile's last pixel)
+            const uint32_t ea = last ? 128u : (nat + 124u + sa < 128u ? nat + 124u + sa : 128u);
+            const uint32_t eb = last ? 128u : (nat + 124u + sb < 128u ? nat + 124u + sb : 128u);
+            const uint32_t ra0 = tq ? (nat + sa < ea ? nat + sa : ea - 1u) : 0u, rb0 = tq ? (nat + sb < eb ? nat + sb : eb - 1u) : 0u;
+            const uint32_t na = ea - ra0, nb = eb - rb0;
+#pragma unroll
+            for (uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t p = half * 64u + lane;
+                const uint32_t xa = ra0 + (p < na ? p : na - 1u), xb = rb0 + (p < nb ? p : nb - 1u);   // window-relative pixels
+                // row a is the pair's odd row (both pixels of a quad are c1) unless it stands in for a missing row b, and vice versa
+                const uint32_t ja = (xa >> 1) * 3u + (has_a ? 0u : 1u + (xa & 1u));
+                const uint32_t jb = (xb >> 1) * 3u + (has_b ? 1u + (xb & 1u) : 0u);
+                const rd_f4 va = st[ja], vb = st[jb];
+                __builtin_nontemporal_store(va, o + (row_a_px + (size_t)q0 * 2u + xa));
+                __builtin_nontemporal_store(vb, o + (row_b_px + (size_t)q0 * 2u + xb));
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if constexpr (FMT == RD_FMT_RGBA_F32) {
             (void)r;
             const rd_f4 *st = stage + (size_t)wave * 192u;       // written by compute_tile
             __builtin_amdgcn_wave_barrier();

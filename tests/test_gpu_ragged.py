@@ -41,7 +41,9 @@ def _fmts(ra):
     return (ra.FMT_RGBA_F32, ra.FMT_RGBA_F16, ra.FMT_RGBA_U8, ra.FMT_RGB_U8)
 
 
-SMALL = [(1, 130), (2, 134), (5, 190), (8, 192), (3, 202), (9, 254), (4, 258), (6, 382), (7, 386), (2, 128), (5, 320)]
+# (250 and 374: W / 2 = 62 T - 61, the f32 surface's shifted-window tiling with a last tile that owns a single quad -- rd_kernels.h,
+#  RD_TILES_SHIFT; every width here that is not a multiple of 4 takes that tiling on the f32 surface)
+SMALL = [(1, 130), (2, 134), (5, 190), (8, 192), (3, 202), (9, 254), (4, 258), (6, 382), (7, 386), (2, 128), (5, 320), (6, 250), (9, 374), (4, 498)]
 
 
 @pytest.mark.parametrize("math", [0, 1])
@@ -213,7 +215,7 @@ print("ok")
 # 16-bit boundaries: 2-byte aligned dword loads, byte-aligned RGB8 dword stores) and rd_develop_lastcol the last column; no
 # entry point refuses a width for its parity any more.
 # ------------------------------------------------------------------------------------------------
-SMALL_ODD = [(7, 131), (1, 129), (2, 131), (5, 191), (4, 257), (3, 385), (6, 1), (5, 3), (4, 7), (9, 127), (2, 65), (8, 193)]
+SMALL_ODD = [(7, 131), (1, 129), (2, 131), (5, 191), (4, 257), (3, 385), (6, 1), (5, 3), (4, 7), (9, 127), (2, 65), (8, 193), (9, 251), (6, 375), (5, 253)]
 
 
 @pytest.mark.parametrize("math", [0, 1])
@@ -251,6 +253,9 @@ def test_batch_odd_widths(gpu_lib, refc, launch_mode):
             _batch(ra, refc, 7, 5, 3, fmt)
             _batch(ra, refc, 6, 1, 2, fmt)
     _batch(ra, refc, 1001, 3001, 2, ra.FMT_RGBA_F32)            # more tiles than resident waves
+    _batch(ra, refc, 9, 251, 4, ra.FMT_RGBA_F32, bands=2)       # the shifted-window tiling's single-quad last tile, odd and even
+    _batch(ra, refc, 8, 374, 3, ra.FMT_RGBA_F32)
+    _batch(ra, refc, 1000, 3002, 2, ra.FMT_RGBA_F32, bands=3)   # W % 4 == 2
     _batch(ra, refc, 1001, 3001, 2, ra.FMT_RGB_U8, bands=3)
 
 
