@@ -695,7 +695,9 @@ def valu_fields(fmt_name, W, H, us_per_frame, valu_ns, n_simd=1024):
     b = isa_budget(fmt_name)
     if not b or not valu_ns:
         return {"valu_issue_frac": None, "valu_note": "profiles/isa_budget.json or rd_measure_valu unavailable"}
-    tiles = (H // 2 + 1) * ((W // 2 + 63) // 64)
+    # tiles per frame as librawdev cuts them (rawdev.hip, rd_tiles_per_unit): 64-quad tiles; 62 owned quads per tile for the
+    # f32 surface's shifted-window tiling (W % 4 != 0, W >= 128)
+    tiles = (H // 2 + 1) * ((W // 2 + 61) // 62 if (fmt_name == "f32" and W % 4 and W >= 128) else (W // 2 + 63) // 64)
     issue_us = b["issue_cycles"] / 2.0 * valu_ns * tiles / n_simd / 1e3
     return {"valu_issue_frac": round(issue_us / us_per_frame, 4), "valu_issue_us_per_frame": round(issue_us, 2),
             "valu_issue_cycles_per_tile": b["issue_cycles"], "valu_instructions_per_tile": b["valu_instructions"],
@@ -1177,13 +1179,13 @@ def extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu
     make (the reference renders any size, shaders.rs:181-187) -- beside 6016 x 4016: the same 64-frame batch per surface,
     the two sizes alternating three times on this box, best of each; `ns_per_px_ratio` = ragged / aligned time per PIXEL.
     Round 6: the same for an ODD width (6001 x 4001: whole quads by the export kernel, the last column by rd_develop_lastcol;
-    rows start on odd 16-bit boundaries, no read burst)."""
+    CFA rows start on odd 16-bit boundaries; f32 rows off the 64-byte blocks: shifted store windows)."""
     nf = min(64, len(cfas))
     cr, pr = make_batch(torch, np, ra, dev, Wr, Hr, nf, 1 << 21, 1)
     ca, pa = cfas[:nf], params[:nf]
     out = {"config": f"{nf} x {Wr}x{Hr} (W % 128 = {Wr % 128}: every row pair ends in a pulled-back, overlapping tile; RGBA8 / RGB8 rows are "
                      f"{Wr * 4} / {Wr * 3} bytes, not whole 128-byte lines" + ("; ODD width: one more launch per multi-frame launch for the last "
-                     "column, 2-byte aligned CFA rows, no read burst for the f32 surface" if Wr % 2 else "") + f") beside {nf} x 6016x4016, "
+                     "column, 2-byte aligned CFA rows; the f32 surface stores through 64-byte-aligned shifted windows (RD_TILES_SHIFT)" if Wr % 2 else "") + f") beside {nf} x 6016x4016, "
                      "randomised stacks, fused histogram, strict f32 arithmetic, multi-frame launches"}
     worst = 0.0
     for fmt_name in ("f32", "f16", "u8", "rgb8"):

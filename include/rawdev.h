@@ -223,8 +223,9 @@ typedef struct rd_frame {
  * stream and per thread (the accumulator is private to the context; calls on one context are not re-entrant).
  * Frame sizes: any height, any width (ABI 5: an odd width is taken too -- the export kernel develops the whole 2 x 2 blocks of
  * a row pair and a small second kernel the last column; through ABI 4 it was RD_ERR_UNSUPPORTED); for RD_FMT_RGB_U8 at least
- * 128 pixels.  Every even width from 128 up runs at the full rate, a multiple of 128 or not; an odd width costs 5-8 % on
- * the narrow surfaces and 17-27 % on RGBA-f32, whose 16-byte pixels put every other row half a 32-byte sector off. */
+ * 128 pixels.  Every even width from 128 up runs at the full rate, a multiple of 128 or not; an odd width costs 5-8 %.
+ * (RGBA-f32 at a width that is not a multiple of 4 -- rows that do not start on 64-byte blocks -- takes a tiling of its own
+ * with shifted store windows: 6-8 % instead of the 20-28 % the plain tiling would cost there.) */
 int rd_batch_create(int device, uint32_t width, uint32_t height, uint32_t format,
                     uint32_t with_histogram, rd_batch **out);
 void rd_batch_destroy(rd_batch *b);
