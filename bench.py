@@ -974,7 +974,7 @@ def extra_batch(torch, np, ra, dev, dev_index, fmt_name, cfas, params, W, H, rin
     saved = {k: os.environ.get(k) for k in ("RD_BATCH_PERSISTENT", "RD_BATCH_STREAMS")}
     if tiled:
         os.environ["RD_BATCH_PERSISTENT"] = "0"              # read by rd_batch_create
-        os.environ.setdefault("RD_BATCH_STREAMS", "2")       # the band launches alternate between two streams: the tail of one under the head of the next (+3 %)
+        os.environ.setdefault("RD_BATCH_STREAMS", "2")       # the band launches alternate between two streams, one workgroup per CU each: they run side by side (round 6: -6 %)
     try:
         be = ra.BatchExporter(dev_index, W, H, fmt, True)
     finally:
@@ -1232,7 +1232,7 @@ def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=N
                                            "need no row bands of their own", "multi", valu_ns=valu_ns, launch_diag=True)
     out["config5_shape_f16_tiled"] = extra_batch(torch, np, ra, dev, dev_index, "f16", c5, p5, W5, H5, 4, 8, 2 if n5 > 16 else 3, stream,
                                                  f"the same {n5} x 100 MP frames as BASELINE configs[4] words it: 'tiled multi-launch per frame' -- "
-                                                 "8 row-band launches per frame (RD_BATCH_PERSISTENT=0), alternating between two streams (RD_BATCH_STREAMS=2)", "per_frame", tiled=True)
+                                                 "8 row-band launches per frame (RD_BATCH_PERSISTENT=0), alternating between two streams that share the CU's two workgroup slots (RD_BATCH_STREAMS=2)", "per_frame", tiled=True)
     del c5
     out["ragged_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns)
     out["odd_width"] = extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=valu_ns, Wr=6001, Hr=4001)

@@ -13,13 +13,16 @@ struct rd_batch {
     uint32_t math_mode = RD_MATH_STRICT;
     rd_launch_cfg cfg;
     uint32_t blocks = 0;                       // fixed grid: slab rows stay aligned across launches
-    // RD_BATCH_STREAMS=2: launches alternate between the caller's stream and an internal one (forked from and joined back
-    // into the caller's stream inside rd_batch_develop), so the next frame's workgroups move in as the previous frame's
-    // finish.  Concurrent launches need their own slab rows and ticket counters.  Measured +2.4 % (strict) / -2 %
-    // (contracted) on 256 x 24 MP: not the default.
+    // RD_BATCH_STREAMS=2: the launches of a call alternate between the caller's stream and an internal one (forked from and
+    // joined back into the caller's stream inside rd_batch_develop).  Concurrent launches need their own slab rows and ticket
+    // counters.  Round 1 (one launch per 24 MP frame, two full-size grids): +2.4 % strict / -2 % contracted, not the default.
+    // Round 6: with two lanes every launch takes ONE of the CU's two workgroup slots -- the lanes' launches then run side by
+    // side instead of queueing for slots the other one holds, a lane's next launch moves into the slots its previous one
+    // frees, and there is no chip-wide drain between launches: BASELINE config 5 as worded (8 row-band launches per 100 MP
+    // frame) 248.5 -> 234.1 us per frame (profiles/r06_c5_tiled_ab.txt).
     uint32_t n_streams = 1;
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux[1] = { nullptr };
+    hipEvent_t ev_fork = nullptr, ev_join[1] = { nullptr };
     unsigned long long *slab64 = nullptr;      // n_streams x blocks x 768
     rd_scratch scratch;                        // per stream: ticket counters
     // Multi-frame launches (the default; RD_BATCH_PERSISTENT=0 falls back to one launch per frame / row band): the
@@ -110,8 +113,14 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
     b->cfg.wg_per_cu_hist = rd_env_u32("RD_WG_PER_CU_HIST", 2);      // experiment builds with a smaller RD_BLOCK only
     b->identity_ok = rd_identity_map(w) && rd_identity_map(h);
     if (!b->identity_ok) return rd_fail(RD_ERR_UNSUPPORTED, "export map is not the identity for %ux%u", w, h);
-    b->blocks = rd_blocks_for(b->cfg, items, b->hist);
+    // RD_BATCH_STREAMS=2: two lanes for one-launch-per-frame / row-band calls (implies RD_BATCH_PERSISTENT=0, as ever).  (Tried in
+    // round 6 and dropped, profiles/r06_c5_tiled_ab.txt: four lanes with half-size grids, 317 against 234 us per 100 MP frame; two
+    // lanes for the MULTI-FRAME launches of the headline, 78.7-79.2 against 78.5-79.0 us per frame: nothing to gain, its
+    // launches follow each other without a gap as it is.)
     b->n_streams = rd_env_u32("RD_BATCH_STREAMS", 1) >= 2 ? 2u : 1u;
+    if (b->n_streams > 1 && !getenv("RD_WG_PER_CU") && !getenv("RD_WG_PER_CU_HIST"))
+        b->cfg.wg_per_cu_plain = b->cfg.wg_per_cu_hist = 1;       // the two lanes share the CU's two workgroup slots: one each
+    b->blocks = rd_blocks_for(b->cfg, items, b->hist);
     {
         const char *pe = getenv("RD_BATCH_PERSISTENT");
         b->persistent = !(pe && *pe == '0') && b->n_streams == 1;
@@ -124,10 +133,10 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
         e = hipEventCreateWithFlags(&b->db[j].done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->db[j].uploaded, hipEventDisableTiming);
     }
-    if (b->n_streams > 1) {
-        e = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+    if (b->n_streams > 1 && e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    for (uint32_t k = 0; k + 1u < b->n_streams && e == hipSuccess; ++k) {
+        e = hipStreamCreateWithFlags(&b->aux[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming);
     }
     if (e == hipSuccess && b->hist) {
         const size_t bytes = (size_t)b->n_streams * b->blocks * 768 * sizeof(unsigned long long);
@@ -157,8 +166,8 @@ extern "C" void rd_batch_destroy(rd_batch *b) try
         for (auto &t : b->timeline) { if (t.start) (void)hipEventDestroy(t.start); if (t.end) (void)hipEventDestroy(t.end); }
         for (hipEvent_t e : b->ev_free) if (e) (void)hipEventDestroy(e);
         if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-        if (b->aux) (void)hipStreamDestroy(b->aux);
+        for (hipEvent_t ev : b->ev_join) if (ev) (void)hipEventDestroy(ev);
+        for (hipStream_t a : b->aux) if (a) (void)hipStreamDestroy(a);
     }
     delete b;
 }
@@ -329,18 +338,23 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
     if (bands > units) bands = units;
     hipStream_t lanes[2] = { (hipStream_t)stream, (hipStream_t)stream };
     const bool fork = b->n_streams > 1 && (uint64_t)n * bands > 1u;
+    const uint32_t nl = fork ? b->n_streams : 1u;
     if (fork) {
         RD_HIP(hipEventRecord(b->ev_fork, lanes[0]));
-        RD_HIP(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
-        lanes[1] = b->aux;
+        for (uint32_t k = 1; k < nl; ++k) {
+            RD_HIP(hipStreamWaitEvent(b->aux[k - 1u], b->ev_fork, 0));
+            lanes[k] = b->aux[k - 1u];
+        }
     }
     int rc = RD_OK;
     size_t launch = 0;
     b->last_launches = 0;
     rd_batch_timing_begin(b);
-    rd_scratch::lease ls[2] = { b->scratch.get(lanes[0], false), rd_scratch::lease{} };
-    if (fork) ls[1] = b->scratch.get(lanes[1], false);
-    if (ls[0].idx < 0 || (fork && ls[1].idx < 0)) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    rd_scratch::lease ls[2];
+    for (uint32_t k = 0; k < nl; ++k) {
+        ls[k] = b->scratch.get(lanes[k], false);
+        if (ls[k].idx < 0) return rd_fail(RD_ERR_OOM, "scheduler state allocation failed");
+    }
     for (size_t f = 0; f < n && rc == RD_OK; ++f) {
         const rd_frame &fr = frames[f];
         if (!fr.cfa_dev || !fr.out_dev) { rc = rd_fail(RD_ERR_INVALID_ARG, "frame %zu: NULL device pointer", f); break; }
@@ -352,7 +366,7 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
         for (uint32_t k = 0; k < bands && rc == RD_OK; ++k, ++launch) {
             const uint32_t u0 = (uint32_t)(((uint64_t)units * k) / bands);
             const uint32_t u1 = (uint32_t)(((uint64_t)units * (k + 1)) / bands);
-            const size_t lane = fork ? (launch & 1u) : 0u;
+            const size_t lane = launch % nl;
             unsigned long long *slab = b->slab64 ? b->slab64 + lane * (size_t)b->blocks * 768u : nullptr;
             rd_batch_timed timed(b, lanes[lane]);
             rc = rd_enqueue_render(b->cfg, fr.cfa_dev, b->w, b->h, b->w, b->h, b->fmt, fr.out_dev, u, true, u0, u1,
@@ -360,11 +374,10 @@ extern "C" int rd_batch_develop(rd_batch *b, const rd_frame *frames, size_t n, u
             if (rc == RD_OK) b->last_launches += 1;
         }
     }
-    b->scratch.used(ls[0], lanes[0], rc != RD_OK);
-    if (fork) b->scratch.used(ls[1], lanes[1], rc != RD_OK);
-    if (fork) {                                  // join even after an error: what was enqueued stays ordered
-        RD_HIP(hipEventRecord(b->ev_join, b->aux));
-        RD_HIP(hipStreamWaitEvent(lanes[0], b->ev_join, 0));
+    for (uint32_t k = 0; k < nl; ++k) b->scratch.used(ls[k], lanes[k], rc != RD_OK);
+    for (uint32_t k = 1; k < nl; ++k) {          // join even after an error: what was enqueued stays ordered
+        RD_HIP(hipEventRecord(b->ev_join[k - 1u], lanes[k]));
+        RD_HIP(hipStreamWaitEvent(lanes[0], b->ev_join[k - 1u], 0));
     }
     return rc;
 }
