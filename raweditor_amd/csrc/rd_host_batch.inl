@@ -74,14 +74,19 @@ struct rd_batch_timed {                        // RAII around ONE launch on stre
         if (!b->timing_keep) return;
         tl.start = rd_batch_timing_event(b); tl.end = rd_batch_timing_event(b); tl.call = b->timing_call;
         on = tl.start && tl.end && hipEventRecord(tl.start, s) == hipSuccess;
-        if (!on) { if (tl.start) b->ev_free.push_back(tl.start); if (tl.end) b->ev_free.push_back(tl.end); }
+        if (!on) { if (tl.start) (void)hipEventDestroy(tl.start); if (tl.end) (void)hipEventDestroy(tl.end); }
     }
-    ~rd_batch_timed()
+    ~rd_batch_timed()                          // (a destructor: nothing may leave it)
     {
         if (!on) return;
         (void)hipEventRecord(tl.end, s);
-        b->timeline.push_back(tl);             // capacity reserved by rd_batch_set_launch_timing for 64 launches per call; beyond
-    }                                          // that a failed growth is caught at the C boundary (the events leak until destroy)
+        try {
+            b->timeline.push_back(tl);         // capacity reserved by rd_batch_set_launch_timing for 64 launches per call
+        } catch (...) {                        // beyond it a failed growth costs this launch its record, nothing else
+            (void)hipEventDestroy(tl.start);
+            (void)hipEventDestroy(tl.end);
+        }
+    }
 };
 
 extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt, uint32_t with_histogram,
