@@ -12,7 +12,9 @@ the oracle:
     launch modes and the export ring;
   * whole frames at 6000 x 4000 and 8256 x 5504 (and a W % 4 == 2 strip, 6002 x 402): every byte of the f32, f16, RGBA8
     and RGB8 surfaces and the exact histogram; the same through the 8-band host render and through a multi-frame launch;
-  * RD_TILES=overlap on a width that needs no overlap (the instance's degenerate case).
+  * RD_TILES=overlap on a width that needs no overlap (the instance's degenerate case);
+  * round 6: odd widths (whole quads + rd_develop_lastcol) on every entry point, and the f32 surface's shifted-window tiling
+    (RD_TILES_SHIFT: every width here that is not a multiple of 4, its edge widths 250 / 251 / 374 / 375 among them).
 """
 import numpy as np
 import pytest
