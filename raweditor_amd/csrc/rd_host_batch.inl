@@ -38,6 +38,8 @@ struct rd_batch {
         hipEvent_t uploaded = nullptr;         // after the copy that filled it (a later call may come on another stream)
         bool valid = false;
     } db[2];
+    hipStream_t up = nullptr;                  // the descriptor uploads' own stream (round 6): a copy need not queue behind the launches
+                                               // already on the caller's stream -- it only has to land before THIS call's first launch
     int db_last = 1;
     uint32_t last_launches = 0;                // fused launches enqueued by the last rd_batch_develop call
     // Launch timing (measurement aid, rd_batch_set_launch_timing): a HIP event pair around every fused launch of the last
@@ -138,6 +140,7 @@ extern "C" int rd_batch_create(int device, uint32_t w, uint32_t h, uint32_t fmt,
         e = hipEventCreateWithFlags(&b->db[j].done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->db[j].uploaded, hipEventDisableTiming);
     }
+    if (e == hipSuccess && b->persistent) e = hipStreamCreateWithFlags(&b->up, hipStreamNonBlocking);
     if (b->n_streams > 1 && e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
     for (uint32_t k = 0; k + 1u < b->n_streams && e == hipSuccess; ++k) {
         e = hipStreamCreateWithFlags(&b->aux[k], hipStreamNonBlocking);
@@ -171,6 +174,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) try
         for (auto &t : b->timeline) { if (t.start) (void)hipEventDestroy(t.start); if (t.end) (void)hipEventDestroy(t.end); }
         for (hipEvent_t e : b->ev_free) if (e) (void)hipEventDestroy(e);
         if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+        if (b->up) (void)hipStreamDestroy(b->up);
         for (hipEvent_t ev : b->ev_join) if (ev) (void)hipEventDestroy(ev);
         for (hipStream_t a : b->aux) if (a) (void)hipStreamDestroy(a);
     }
@@ -291,13 +295,17 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
             d.cap = cap;
         }
         memcpy(d.host, tmp.data(), n * sizeof(rd_frame_desc));
-        RD_HIP(hipMemcpyAsync(d.dev, d.host, n * sizeof(rd_frame_desc), hipMemcpyHostToDevice, s));
-        RD_HIP(hipEventRecord(d.uploaded, s));
+        // on the batch's own upload stream: the array is free (its readers finished: `done` above), so the copy starts at once,
+        // under whatever launches of the previous call are still queued on s, instead of sitting between two kernels of s
+        // (a copy-engine transfer there is a bubble of ~15 us per call: 0.5 % of a 64-frame narrow batch, HISTORY round 5)
+        static const bool inline_upload = rd_env_u32("RD_DESC_UPLOAD_INLINE", 0) != 0;       // A/B: the copy on s itself, as through round 5
+        hipStream_t us = (b->up && !inline_upload) ? b->up : s;
+        RD_HIP(hipMemcpyAsync(d.dev, d.host, n * sizeof(rd_frame_desc), hipMemcpyHostToDevice, us));
+        RD_HIP(hipEventRecord(d.uploaded, us));
         d.n = n;
         d.valid = true;
-    } else {
-        RD_HIP(hipStreamWaitEvent(s, b->db[j].uploaded, 0));     // reused array: its copy may have been enqueued on another stream
     }
+    RD_HIP(hipStreamWaitEvent(s, b->db[j].uploaded, 0));         // (a reused array's copy may have been enqueued by a call on another stream)
     b->db_last = j;
     const rd_frame_desc *descs = b->db[j].dev;
 
