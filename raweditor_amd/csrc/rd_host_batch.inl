@@ -428,17 +428,23 @@ extern "C" int rd_batch_measure_clock(rd_batch *b, const rd_frame *frames, size_
                                            "multi-frame launches only");
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
-    struct res { uint32_t *dev = nullptr; ~res() { if (dev) (void)hipFree(dev); } } r;
+    // (the stamp buffer is released only after the stream that writes it has been waited for -- also when something below throws)
+    struct res {
+        uint32_t *dev = nullptr; hipStream_t s = nullptr;
+        ~res() { if (dev) { (void)hipStreamSynchronize(s); (void)hipFree(dev); } }
+    } r;
+    r.s = (hipStream_t)stream;
     const size_t bytes = (size_t)b->blocks * 2u * sizeof(uint32_t);
+    std::vector<uint32_t> st((size_t)b->blocks * 2u);            // host side first: nothing is in flight if this fails
+    std::vector<double> ghz, us;
+    ghz.reserve(b->blocks); us.reserve(b->blocks);
     RD_HIP(hipMalloc((void **)&r.dev, bytes));
     RD_HIP(hipMemsetAsync(r.dev, 0, bytes, (hipStream_t)stream));
     int rc = rd_batch_develop_multi(b, frames, n, (hipStream_t)stream, false, r.dev);
-    std::vector<uint32_t> st((size_t)b->blocks * 2u);
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);     // before r.dev goes, whatever rc says
     if (rc) return rc;
     RD_HIP(e);
     RD_HIP(hipMemcpy(st.data(), r.dev, bytes, hipMemcpyDeviceToHost));
-    std::vector<double> ghz, us;
     for (uint32_t k = 0; k < b->blocks; ++k)
         if (st[2u * k] && st[2u * k + 1u]) { ghz.push_back((double)st[2u * k] / (double)st[2u * k + 1u] * 0.1); us.push_back((double)st[2u * k + 1u] * 0.01); }
     if (ghz.empty()) return rd_fail(RD_ERR_HIP, "no workgroup left a clock stamp");
