@@ -38,6 +38,11 @@ def main():
         # round 5 (appended: the random stream of the cases above is unchanged): a width that is not a multiple of the export
         # kernel's 128-pixel tile -- 134 = one whole tile + a last tile pulled back over 61 of its quads -- and an odd height
         dict(name="ragged_11x134", h=11, w=134, params="random", wb=WB_DAYLIGHT, cm=CM_TEST),
+        # round 6 (appended likewise): an ODD width of more than one tile -- the export kernel takes its 65 whole quads, a second
+        # kernel the last column, and the f32 surface stores through shifted windows (W % 4 != 0) -- and an even width with
+        # W % 4 == 2 whose W / 2 = 62 T - 61 (the shifted-window tiling's last tile owns a single quad)
+        dict(name="odd_7x131", h=7, w=131, params="random", wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="shift_6x250", h=6, w=250, params="random", wb=WB_DAYLIGHT, cm=CM_IDENTITY),
     ]
     out = {}
     for s in spec:
