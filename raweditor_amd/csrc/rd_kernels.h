@@ -1350,16 +1350,25 @@ rd_quads_body(const uint16_t *__restrict__ cfa_arg, void *__restrict__ out_arg, 
             const uint32_t eb = last ? 128u : (nat + 124u + sb < 128u ? nat + 124u + sb : 128u);
             const uint32_t ra0 = tq ? (nat + sa < ea ? nat + sa : ea - 1u) : 0u, rb0 = tq ? (nat + sb < eb ? nat + sb : eb - 1u) : 0u;
             const uint32_t na = ea - ra0, nb = eb - rb0;
+            const uint32_t ma = na - 1u, mb = nb - 1u;
+            RD_GLOBAL rd_f4 *oa = o + (row_a_px + (size_t)q0 * 2u), *ob = o + (row_b_px + (size_t)q0 * 2u);   // wave-uniform bases (SALU)
 #pragma unroll
             for (uint32_t half = 0; half < 2u; ++half) {
                 const uint32_t p = half * 64u + lane;
-                const uint32_t xa = ra0 + (p < na ? p : na - 1u), xb = rb0 + (p < nb ? p : nb - 1u);   // window-relative pixels
-                // row a is the pair's odd row (both pixels of a quad are c1) unless it stands in for a missing row b, and vice versa
-                const uint32_t ja = (xa >> 1) * 3u + (has_a ? 0u : 1u + (xa & 1u));
-                const uint32_t jb = (xb >> 1) * 3u + (has_b ? 1u + (xb & 1u) : 0u);
-                const rd_f4 va = st[ja], vb = st[jb];
-                __builtin_nontemporal_store(va, o + (row_a_px + (size_t)q0 * 2u + xa));
-                __builtin_nontemporal_store(vb, o + (row_b_px + (size_t)q0 * 2u + xb));
+                const uint32_t xa = ra0 + (p < ma ? p : ma), xb = rb0 + (p < mb ? p : mb);   // window-relative pixels (one v_min each)
+                __builtin_assume(xa < 128u && xb < 128u);        // (inside the tile: the byte offset fits the 32-bit lane offset of a store)
+                // row a is the pair's odd row: both pixels of a quad are c1; row b: c2 / c3 by the pixel's parity
+                uint32_t ia = (xa >> 1) * 3u, ib = (xb >> 1) * 3u + 1u + (xb & 1u);
+                if (__builtin_expect(!(has_a && has_b), 0)) {    // first / last unit only (wave-uniform): a missing row is the other one
+                    // again -- row_a_px == row_b_px then, so is the shift, so xa == xb: only the stage INDEX has to follow (a branch, as
+                    // in the f16 path: as selects it would cost every tile)
+                    if (!has_a) ia = ib; else ib = ia;
+                    asm volatile("" : "+v"(ia), "+v"(ib));
+                }
+                const rd_f4 va = st[ia], vb = st[ib];
+                // (wave-uniform base + a 32-bit byte offset per lane: global_store_dwordx4 v_off, v[data], s[base], as the other tilings)
+                __builtin_nontemporal_store(va, reinterpret_cast<RD_GLOBAL rd_f4 *>(reinterpret_cast<RD_GLOBAL char *>(oa) + (uint32_t)(xa * 16u)));
+                __builtin_nontemporal_store(vb, reinterpret_cast<RD_GLOBAL rd_f4 *>(reinterpret_cast<RD_GLOBAL char *>(ob) + (uint32_t)(xb * 16u)));
             }
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (FMT == RD_FMT_RGBA_F32) {
