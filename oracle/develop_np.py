@@ -144,8 +144,8 @@ def pixel_map(w, h, tw, th, zoom, pan_x, pan_y):
         iny = (ty >= 0) & (ty <= 1)
         px = np.where(inx, tx * F(w), F(0)).astype(np.int32)
         py = np.where(iny, ty * F(h), F(0)).astype(np.int32)
-    px = np.minimum(px, w - 1)
-    py = np.minimum(py, h - 1)
+    # tx == 1.0 exactly -> px == w (one past the texture): kept as it is, the parity of shaders.rs:115-118 is taken on it;
+    # every load clamps (demosaic)
     PX, PY = np.meshgrid(px, py)
     inside = np.logical_and.outer(iny, inx)
     return PX, PY, inside
@@ -163,7 +163,7 @@ def demosaic(cfa, PX, PY, black_level=0):
 
     row_even = ((PY + 1) % 2) == 0       # parity is taken on py+1 (shaders.rs:115)
     col_even = (PX % 2) == 0
-    c = v[PY, PX]
+    c = tap(0, 0)                        # (the centre load of :106 sees px == w when tex_coords.x == 1.0: lowered as a clamp)
     # four cases of shaders.rs:127-155
     r = np.where(row_even, np.where(col_even, tap(0, 1), tap(-1, 1)),
                  np.where(col_even, c, tap(-1, 0)))

@@ -253,8 +253,10 @@ void ref_pixel(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *
     }
     int32_t px = (int32_t)(tx * (float)w);
     int32_t py = (int32_t)(ty * (float)h);
-    if (px > (int32_t)w - 1) px = (int32_t)w - 1;  /* tx == 1.0 exactly: defined as clamp */
-    if (py > (int32_t)h - 1) py = (int32_t)h - 1;
+    /* tx == 1.0 exactly gives px == w, one past the texture, and the shader carries that coordinate on (:184-192): the Bayer
+     * parity is taken on it as it is; only the loads see a border -- get_neighbor clamps (:164-167) and the centre load of
+     * :106 is out of bounds, which this repository lowers as a clamp too (tap()).  Pinned by the evaluated shader text:
+     * tests/golden/wgsl_golden.npz case tex_coord_one. */
     float c[3];
     debayer(cfa, (int32_t)w, (int32_t)h, px, py, u->black_level, c);
     if (u->math_mode == REF_MATH_CONTRACTED) colour_stack_contracted(u, pow_mode, c);

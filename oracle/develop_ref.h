@@ -16,10 +16,19 @@
  *
  * PARITY PINNING: the reference holds no golden vectors, fixtures or tests for this path
  * (its 7 unit tests never touch src/gpu/), it is Rust+WGSL (no toolchain in the image), and
- * no NEF sample ships with it.  The oracle is therefore pinned by (i) the analytic
- * known-answer vectors K1..K10 of SURVEY.md section 8c (tests/golden/), derived by hand from the
- * shader text, and (ii) agreement with an independently written numpy twin
- * (oracle/develop_np.py).  Against the reference's own outputs: "parity unpinned".
+ * no NEF sample ships with it.  What pins the oracle:
+ *   (i)   the reference's own shader TEXT, executed: tools/make_wgsl_golden.py reads the WGSL string
+ *         of shaders.rs:14-267 where it lies and runs vs_main / fs_main through the WGSL evaluator
+ *         of oracle/wgsl_eval.py (written from the WGSL specification; it holds no reference text);
+ *         the vectors are tests/golden/wgsl_golden.npz and this file reproduces them bit for bit in
+ *         both pow modes (tests/test_wgsl_pin_cpu.py) -- operation order, constants, selection table,
+ *         abstract-float folding and conversions are therefore the text's, not a reading of it;
+ *   (ii)  the analytic known-answer vectors K1..K10 of SURVEY.md section 8c (tests/golden/);
+ *   (iii) agreement with an independently written numpy twin (oracle/develop_np.py).
+ * What stays "parity unpinned": the behaviour WGSL leaves to the implementation (pow accuracy,
+ * fma contraction, dot order, mix form, min/max of NaN, out-of-bounds textureLoad, the rasteriser's
+ * interpolation) -- fixed here as named choices that only a run of the
+ * reference on wgpu could confirm -- and the fixed-function UNORM8 / binary16 conversions.
  */
 #ifndef DEVELOP_REF_H
 #define DEVELOP_REF_H

@@ -1735,8 +1735,8 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
         if (tx >= 0.0f && tx <= 1.0f && ty >= 0.0f && ty <= 1.0f) {
             int32_t px = (int32_t)(tx * (float)W);
             int32_t py = (int32_t)(ty * (float)H);
-            px = px > (int32_t)W - 1 ? (int32_t)W - 1 : px;
-            py = py > (int32_t)H - 1 ? (int32_t)H - 1 : py;
+            // tx == 1.0 exactly: px == W, one past the frame.  The shader carries that coordinate on -- the Bayer parity is taken on
+            // it -- and only its loads see the border (rd_tap clamps every one, the centre's included).
             c = rd_develop_px<MATH, Q8ONLY>(cfa, W, H, px, py, u);   // Q8ONLY: linear values; rd_q8_gamma finishes (out-of-bounds pixels stay 0 -> code 0)
         }
         uint32_t qr = 0, qg = 0, qb = 0;
