@@ -45,33 +45,48 @@ EXPORT_CASES = [c for c in CASES if c["zoom"] == 1.0 and c["pan"] == [0.0, 0.0] 
                 and c["th"] == c["cfa"].shape[0] and c["cfa"].shape[1] >= 128]
 
 
+def _groups():
+    """Export cases grouped by frame size: one multi-frame launch per group."""
+    by = {}
+    for c in EXPORT_CASES:
+        by.setdefault(c["cfa"].shape, []).append(c)
+    return sorted(by.items())
+
+
 def test_fixture_holds_export_kernel_widths():
     assert {c["name"] for c in EXPORT_CASES} >= {"export_tile_5x134", "export_odd_4x131", "export_shift_3x250"}
+    assert max(len(g) for _, g in _groups()) >= 4                     # different frames of one size, for one launch
 
 
-@pytest.mark.parametrize("case", EXPORT_CASES, ids=[c["name"] for c in EXPORT_CASES])
-def test_batch_entry_reproduces_the_evaluated_shader(gpu_lib, refc, case):
-    """Three frames per launch (the same CFA and stack in each: the fixture holds one frame per case), every surface format."""
+@pytest.mark.parametrize("shape,group", _groups(), ids=[f"{s[1]}x{s[0]}" for s, _ in _groups()])
+def test_batch_entry_reproduces_the_evaluated_shader(gpu_lib, refc, shape, group):
+    """One multi-frame launch per frame size and surface format: every frame of the group (its own CFA and slider stack; white
+    balance and matrix are per frame too) plus a repeat of the first one, so a group of one still launches two frames."""
     ra = gpu_lib
-    h, w = case["cfa"].shape
-    exp = case["f32_pinned"]
-    exp8 = refc.pack_u8(exp)
-    n = 3
-    for fmt, dt, ch, want in ((ra.FMT_RGBA_F32, np.uint32, 4, bits(exp)),
-                              (ra.FMT_RGBA_F16, np.uint16, 4, refc.pack_f16(exp).view(np.uint16)),
-                              (ra.FMT_RGBA_U8, np.uint8, 4, exp8), (ra.FMT_RGB_U8, np.uint8, 3, exp8[..., :3])):
-        d_in = [DevBuf.from_array(case["cfa"]) for _ in range(n)]
+    h, w = shape
+    cases = group + group[:1]
+    n = len(cases)
+    exp = [c["f32_pinned"] for c in cases]
+    exp8 = [refc.pack_u8(e) for e in exp]
+    want_hist = sum(refc.histogram(e).reshape(-1).astype(np.uint64) for e in exp8)
+    for fmt, dt, ch, want in ((ra.FMT_RGBA_F32, np.uint32, 4, [bits(e) for e in exp]),
+                              (ra.FMT_RGBA_F16, np.uint16, 4, [refc.pack_f16(e).view(np.uint16) for e in exp]),
+                              (ra.FMT_RGBA_U8, np.uint8, 4, exp8), (ra.FMT_RGB_U8, np.uint8, 3, [e[..., :3] for e in exp8])):
+        d_in = [DevBuf.from_array(c["cfa"]) for c in cases]
         d_out = [DevBuf(h * w * ra.BYTES_PER_PIXEL[fmt]) for _ in range(n)]
         d_hist = DevBuf(768 * 8)
         be = ra.BatchExporter(0, w, h, fmt, True)
-        frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], [ra.EditParams(**case["params"])] * n,
-                                case["wb"], case["cm"])
+        frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], [ra.EditParams(**c["params"]) for c in cases],
+                                cases[0]["wb"], cases[0]["cm"])
+        for f, c in zip(frames, cases):                               # rd_frame carries its own white balance and matrix
+            f.wb_multipliers[:] = c["wb"]
+            f.color_matrix[:] = c["cm"]
         be.develop(frames)
         be.histogram(d_hist.ptr)
         sync()
-        for o in d_out:
-            assert np.array_equal(o.to_array(dt, (h, w, ch)), want), (case["name"], fmt)
-        assert np.array_equal(d_hist.to_array(np.uint64, (768,)), refc.histogram(exp8).reshape(-1).astype(np.uint64) * n)
+        for c, o, e in zip(cases, d_out, want):
+            assert np.array_equal(o.to_array(dt, (h, w, ch)), e), (c["name"], fmt)
+        assert np.array_equal(d_hist.to_array(np.uint64, (768,)), want_hist), fmt
         be.close()
         for b in d_in + d_out + [d_hist]:
             b.free()

@@ -27,6 +27,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -65,43 +66,53 @@ def range_end_params(which):
     return out
 
 
-def spec(rng):
+def case_rng(name):
+    """Every case draws from its own stream, keyed by its name: adding a case never changes another one's vectors."""
+    return np.random.default_rng([SEED, zlib.crc32(name.encode())])
+
+
+def spec():
+    R = "random"
     s = [
         dict(name="default_8x12", h=8, w=12, params={}, wb=(1, 1, 1, 1), cm=CM_IDENTITY),
-        dict(name="random_12x16", h=12, w=16, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST),
-        dict(name="random_odd_7x9", h=7, w=9, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_IDENTITY),
-        dict(name="one_pixel", h=1, w=1, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST),
-        dict(name="u16_full_range_8x10", h=8, w=10, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST, hi=65536),
-        dict(name="preview_zoom_pan", h=12, w=16, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST,
+        dict(name="random_12x16", h=12, w=16, params=R, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="random_odd_7x9", h=7, w=9, params=R, wb=WB_DAYLIGHT, cm=CM_IDENTITY),
+        dict(name="one_pixel", h=1, w=1, params=R, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="u16_full_range_8x10", h=8, w=10, params=R, wb=WB_DAYLIGHT, cm=CM_TEST, hi=65536),
+        dict(name="preview_zoom_pan", h=12, w=16, params=R, wb=WB_DAYLIGHT, cm=CM_TEST,
              tw=11, th=7, zoom=1.75, pan=(0.125, -0.0625)),
         dict(name="zoomed_out_border", h=10, w=14, params={}, wb=WB_DAYLIGHT, cm=CM_IDENTITY,
              tw=20, th=12, zoom=0.5, pan=(0.0, 0.0)),
         # tex_coords reach exactly 1.0 in the second column and row: pixel_coords = (W, H), one past the texture
-        dict(name="tex_coord_one", h=6, w=8, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST,
-             tw=2, th=2, zoom=0.5, pan=(0.0, 0.0)),
-        dict(name="downsampled_preview", h=12, w=18, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST, tw=7, th=5),
-    ]
-    # widths the export kernel takes (W >= 128): one whole 128-pixel tile + a ragged tail; an ODD width (last column by the
-    # second kernel, shifted-window stores on the f32 surface); W % 4 == 2 with the shifted tiling's last tile owning one quad
-    s += [
-        dict(name="export_tile_5x134", h=5, w=134, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST),
-        dict(name="export_odd_4x131", h=4, w=131, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST),
-        dict(name="export_shift_3x250", h=3, w=250, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_IDENTITY),
-        dict(name="random_32x48", h=32, w=48, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="tex_coord_one", h=6, w=8, params=R, wb=WB_DAYLIGHT, cm=CM_TEST, tw=2, th=2, zoom=0.5, pan=(0.0, 0.0)),
+        dict(name="downsampled_preview", h=12, w=18, params=R, wb=WB_DAYLIGHT, cm=CM_TEST, tw=7, th=5),
+        dict(name="random_32x48", h=32, w=48, params=R, wb=WB_DAYLIGHT, cm=CM_TEST),
+        # widths the export kernel takes (W >= 128): one whole 128-pixel tile + a ragged tail (four frames of that size, each with
+        # its own CFA and stack: a multi-frame launch of the batch entry is checked on DIFFERENT frames); an ODD width (last
+        # column by the second kernel, shifted-window stores on the f32 surface); W % 4 == 2 with the shifted tiling's last tile
+        # owning one quad
+        dict(name="export_tile_5x134", h=5, w=134, params=R, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="export_tile_5x134_b", h=5, w=134, params=R, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="export_tile_5x134_c", h=5, w=134, params=R, wb=WB_DAYLIGHT, cm=CM_IDENTITY),
+        dict(name="export_tile_5x134_d", h=5, w=134, params={}, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="export_odd_4x131", h=4, w=131, params=R, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="export_shift_3x250", h=3, w=250, params=R, wb=WB_DAYLIGHT, cm=CM_IDENTITY),
     ]
     for which in range(4):
         s.append(dict(name=f"range_ends_{which}", h=6, w=8, params=range_end_params(which), wb=WB_DAYLIGHT, cm=CM_TEST))
     for n in range(12):
-        s.append(dict(name=f"random_stack_{n}", h=6, w=10, params=random_params(rng), wb=WB_DAYLIGHT, cm=CM_TEST))
+        s.append(dict(name=f"random_stack_{n}", h=6, w=10, params=R, wb=WB_DAYLIGHT, cm=CM_TEST))
     return s
 
 
 def main():
     src = shader_source()
-    rng = np.random.default_rng(SEED)
     out, cases = {}, []
     t0 = time.time()
-    for s in spec(rng):
+    for s in spec():
+        rng = case_rng(s["name"])
+        if s["params"] == "random":
+            s["params"] = random_params(rng)
         cfa = random_cfa(rng, s["h"], s["w"], s.get("hi", 4096))
         zoom, pan = s.get("zoom", 1.0), s.get("pan", (0.0, 0.0))
         tw, th = s.get("tw", s["w"]), s.get("th", s["h"])
