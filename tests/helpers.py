@@ -17,6 +17,16 @@ def random_params(rng):
     return {k: float(np.float32(rng.uniform(*UI_RANGES[k]))) for k in PARAM_NAMES}
 
 
+MILD_SPAN = {"exposure": 1.0, "contrast": 30.0, "saturation": 40.0, "whites": 0.1, "blacks": 0.03}   # others: 0.3
+
+
+def mild_params(rng):
+    """A mild edit around the defaults: most pixels of a 12-bit frame stay strictly inside (0, 1), where rounding shows (a draw
+    over the whole UI ranges saturates most of them)."""
+    return {k: float(np.float32((1.0 if k == "whites" else 0.0) + rng.uniform(-1.0, 1.0) * MILD_SPAN.get(k, 0.3)))
+            for k in PARAM_NAMES}
+
+
 def random_cfa(rng, h, w, hi=4096):
     return rng.integers(0, hi, (h, w), dtype=np.uint16)
 

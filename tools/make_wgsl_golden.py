@@ -34,7 +34,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import develop_np as dn, wgsl_eval as we, wgsl_render as wr  # noqa: E402
-from tests.helpers import CM_IDENTITY, CM_TEST, PARAM_NAMES, UI_RANGES, WB_DAYLIGHT, random_cfa, random_params  # noqa: E402
+from tests.helpers import (CM_IDENTITY, CM_TEST, PARAM_NAMES, UI_RANGES, WB_DAYLIGHT, mild_params, random_cfa,  # noqa: E402
+                           random_params)
 
 SHADER_FILE = "/root/reference/src/gpu/shaders.rs"
 SHADER_CONST = "PASSTHROUGH_SHADER"
@@ -102,6 +103,20 @@ def spec():
         s.append(dict(name=f"range_ends_{which}", h=6, w=8, params=range_end_params(which), wb=WB_DAYLIGHT, cm=CM_TEST))
     for n in range(12):
         s.append(dict(name=f"random_stack_{n}", h=6, w=10, params=R, wb=WB_DAYLIGHT, cm=CM_TEST))
+    # mild edits (tests/helpers.py: mild_params): most output values strictly inside (0, 1), where every rounding of the stack
+    # shows in the result (the draws over the whole UI ranges above saturate two thirds of theirs)
+    M = "mild"
+    s += [dict(name=f"mild_stack_{n}", h=6, w=10, params=M, wb=WB_DAYLIGHT, cm=CM_TEST) for n in range(8)]
+    s += [
+        dict(name="mild_preview_zoom_pan", h=12, w=16, params=M, wb=WB_DAYLIGHT, cm=CM_TEST, tw=11, th=7, zoom=1.75,
+             pan=(0.125, -0.0625)),
+        dict(name="mild_tex_coord_one", h=6, w=8, params=M, wb=(1, 1, 1, 1), cm=CM_IDENTITY, tw=4, th=4, zoom=0.5, pan=(0.0, 0.0)),
+        dict(name="mild_export_tile_5x134", h=5, w=134, params=M, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="mild_export_odd_4x131", h=4, w=131, params=M, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="mild_export_odd_4x131_b", h=4, w=131, params=M, wb=WB_DAYLIGHT, cm=CM_IDENTITY),
+        dict(name="mild_export_shift_3x250", h=3, w=250, params=M, wb=WB_DAYLIGHT, cm=CM_TEST),
+        dict(name="mild_export_two_tiles_3x262", h=3, w=262, params=M, wb=WB_DAYLIGHT, cm=CM_TEST),
+    ]
     return s
 
 
@@ -113,6 +128,8 @@ def main():
         rng = case_rng(s["name"])
         if s["params"] == "random":
             s["params"] = random_params(rng)
+        elif s["params"] == "mild":
+            s["params"] = mild_params(rng)
         cfa = random_cfa(rng, s["h"], s["w"], s.get("hi", 4096))
         zoom, pan = s.get("zoom", 1.0), s.get("pan", (0.0, 0.0))
         tw, th = s.get("tw", s["w"]), s.get("th", s["h"])

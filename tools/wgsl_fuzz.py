@@ -2,8 +2,8 @@
 """Differential fuzz: the reference's shader text, executed (oracle/wgsl_eval.py), against the C oracle -- build container only.
 
 Random small frames (1 x 1 ... 9 x 12, 12- and 16-bit CFA values, flat and saturated fields among them), random targets, random
-zoom / pan (views that reach the border, tex_coords of exactly 0.0 and 1.0 included), slider stacks inside the UI ranges, far
-outside them and at degenerate points (whites == blacks, contrast = -100, saturation = -100, exposure +-20), random matrices
+zoom / pan (views that reach the border, tex_coords of exactly 0.0 and 1.0 included), slider stacks of mild edits, inside the UI ranges,
+far outside them and at degenerate points (whites == blacks, contrast = -100, saturation = -100, exposure +-20), random matrices
 and white balance.  Every frame is evaluated from the text with both pow flavours and compared BIT FOR BIT with
 oracle/develop_ref.c in the matching pow mode; any difference is printed with its inputs and the run fails.
 
@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import ref_c, wgsl_eval as we, wgsl_render as wr  # noqa: E402
-from tests.helpers import PARAM_NAMES, UI_RANGES  # noqa: E402
+from tests.helpers import MILD_SPAN, PARAM_NAMES, UI_RANGES  # noqa: E402
 from tools.make_wgsl_golden import LOWERINGS, shader_source  # noqa: E402
 
 POW_MODE = {"f32_pinned": ref_c.POW_PINNED, "f32_libm": ref_c.POW_LIBM}
@@ -30,11 +30,13 @@ def f32(x):
 
 
 def draw_params(rng):
-    kind = rng.integers(0, 5)
+    kind = 5 if rng.random() < 0.4 else rng.integers(0, 5)
     p = {}
     for k in PARAM_NAMES:
         lo, hi = UI_RANGES[k]
-        if kind == 0:                                    # inside the UI
+        if kind == 5:                                    # mild edits: most pixels stay strictly inside (0, 1), where rounding shows
+            v = (1.0 if k == "whites" else 0.0) + rng.uniform(-1.0, 1.0) * MILD_SPAN.get(k, 0.3)
+        elif kind == 0:                                  # inside the UI
             v = rng.uniform(lo, hi)
         elif kind == 1:                                  # far outside it
             v = rng.uniform(lo - 5 * (hi - lo), hi + 5 * (hi - lo))
