@@ -10,6 +10,9 @@ specification, and its unit tests (tests/test_wgsl_pin_cpu.py) use shader snippe
 
 What the WGSL specification leaves to the implementation is NOT decided in here; it is passed in as a `Lowering`:
     pow(x, y)                        (accuracy is implementation-defined: "inherited from exp2(y * log2(x))")
+    contraction                      (an implementation may fuse a multiplication into the addition or subtraction that
+                                      consumes it; "none" keeps every rounding, "fuse" models what an LLVM-style compiler
+                                      does with the text: see Lowering)
     dot / matrix * vector            (summation order)
     mix(x, y, a)                     (x * (1 - a) + y * a  or  x + (y - x) * a; the specification allows both)
     min / max / clamp on NaN         (implementation-defined)
@@ -30,6 +33,7 @@ from __future__ import annotations
 
 import math
 import re
+from fractions import Fraction
 
 import numpy as np
 
@@ -178,11 +182,61 @@ def _fmin(a, b):
     return a if a < b else b
 
 
+class Product(np.float32):
+    """An f32 that remembers it is round(x * y): under contraction="fuse" an addition or subtraction that consumes it computes
+    fma(x, y, other) instead.  Any other use sees a plain f32 (numpy arithmetic on it returns numpy.float32)."""
+
+
+def _product(x, y):
+    with np.errstate(all="ignore"):
+        p = Product(x * y)
+    p.factors = (x, y)
+    return p
+
+
+def fma_f32(x, y, z):
+    """round(x * y + z) with ONE rounding to nearest even (exact rational arithmetic; NaN / infinity by the float rules)."""
+    x, y, z = float(x), float(y), float(z)
+    if not (math.isfinite(x) and math.isfinite(y) and math.isfinite(z)):
+        with np.errstate(all="ignore"):
+            return F32(np.float64(x) * np.float64(y) + np.float64(z))
+    exact = Fraction(x) * Fraction(y) + Fraction(z)
+    if exact == 0:
+        with np.errstate(all="ignore"):
+            return F32(np.float64(x) * np.float64(y) + np.float64(z))       # the sign of an exact zero follows the float rules
+    mag = abs(exact)
+    e = mag.numerator.bit_length() - mag.denominator.bit_length()
+    if Fraction(2) ** e > mag:
+        e -= 1
+    e = max(e, -126)                                         # below 2^-126 the quantum stays 2^-149 (subnormals)
+    quantum = Fraction(2) ** (e - 23)
+    n = mag / quantum
+    m = n.numerator // n.denominator
+    rem = n - m
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (m & 1)):
+        m += 1
+    value = m * quantum
+    if value >= Fraction(2) ** 128:
+        return F32(-np.inf if exact < 0 else np.inf)
+    r = float(value)                                         # exact: at most 25 significant bits
+    return F32(-r if exact < 0 else r)
+
+
 class Lowering:
-    """Implementation-defined behaviour, made explicit.  `pow` maps two numpy.float32 to one; the rest are named choices."""
+    """Implementation-defined behaviour, made explicit.  `pow` maps two numpy.float32 to one; the rest are named choices.
+
+    contraction = "none": every multiplication and addition rounds on its own.
+    contraction = "fuse": an f32 addition or subtraction one of whose operands is the (not otherwise transformed) result of
+    an f32 multiplication becomes one fma -- the left operand's product first, then the right one's, as LLVM's DAG combiner
+    orders them (fadd (fmul x, y), z -> fma x, y, z;  fadd x, (fmul y, z) -> fma y, z, x;  fsub (fmul x, y), z ->
+    fma x, y, -z;  fsub x, (fmul y, z) -> fma -y, z, x), through `let` bindings, function calls, vector components and unary
+    minus, whatever the number of uses (the aggressive form).  dot and mix are built from the same mul / add / sub."""
 
     def __init__(self, pow, dot_order="left_to_right", mix_form="x*(1-a)+y*a", nan_minmax="other_operand",
-                 nan_to_int=0, texture_oob="clamp"):
+                 nan_to_int=0, texture_oob="clamp", contraction="none"):
+        if contraction not in ("none", "fuse"):
+            raise WgslError("unknown contraction rule")
+        self.fuse = contraction == "fuse"
         if dot_order != "left_to_right":
             raise WgslError("only left-to-right dot products are implemented")
         if mix_form not in ("x*(1-a)+y*a", "x+(y-x)*a"):
@@ -194,16 +248,45 @@ class Lowering:
         self.pow, self.mix_form, self.nan_to_int, self.texture_oob = pow, mix_form, nan_to_int, texture_oob
 
     # f32 scalars in, f32 scalar out
+    def mul(self, a, b):
+        if self.fuse:
+            return _product(a, b)
+        with np.errstate(all="ignore"):
+            return a * b
+
+    def add(self, a, b):
+        if self.fuse:
+            if isinstance(a, Product):
+                return fma_f32(*a.factors, b)
+            if isinstance(b, Product):
+                return fma_f32(*b.factors, a)
+        with np.errstate(all="ignore"):
+            return F32(a) + F32(b)
+
+    def sub(self, a, b):
+        if self.fuse:
+            if isinstance(a, Product):
+                return fma_f32(*a.factors, -F32(b))
+            if isinstance(b, Product):
+                return fma_f32(-b.factors[0], b.factors[1], a)
+        with np.errstate(all="ignore"):
+            return F32(a) - F32(b)
+
+    def neg(self, a):
+        if self.fuse and isinstance(a, Product):
+            return _product(-a.factors[0], a.factors[1])
+        return -F32(a)
+
     def dot(self, a, b):
-        acc = a[0] * b[0]
+        acc = self.mul(a[0], b[0])
         for x, y in zip(a[1:], b[1:]):
-            acc = acc + x * y
-        return acc
+            acc = self.add(acc, self.mul(x, y))
+        return F32(acc) if not self.fuse else acc
 
     def mix(self, x, y, a):
         if self.mix_form == "x*(1-a)+y*a":
-            return x * (F32(1.0) - a) + y * a
-        return x + (y - x) * a
+            return self.add(self.mul(x, self.sub(F32(1.0), a)), self.mul(y, a))
+        return self.add(x, self.mul(self.sub(y, x), a))
 
 
 def pow_f64_rounded(x, y):
@@ -514,8 +597,8 @@ class _Return(Exception):
 _SWIZZLE = {"x": 0, "y": 1, "z": 2, "w": 3, "r": 0, "g": 1, "b": 2, "a": 3}
 
 
-def _scalar_binop(op, k, a, b):
-    """a, b already of kind k.  Returns (kind, value)."""
+def _scalar_binop(op, k, a, b, low=None):
+    """a, b already of kind k.  Returns (kind, value).  `low`: the Lowering (f32 mul / add / sub go through it)."""
     if op in ("==", "!=", "<", ">", "<=", ">="):
         r = {"==": a == b, "!=": a != b, "<": a < b, ">": a > b, "<=": a <= b, ">=": a >= b}[op]
         return "bool", bool(r)
@@ -526,6 +609,8 @@ def _scalar_binop(op, k, a, b):
             return "bool", a or b
         raise WgslError(f"operator {op} on bool")
     if k == "f32":
+        if low is not None and op in ("+", "-", "*"):
+            return k, {"+": low.add, "-": low.sub, "*": low.mul}[op](a, b)
         with np.errstate(all="ignore"):
             if op == "+":
                 return k, a + b
@@ -888,10 +973,9 @@ class Module:
             raise WgslError("unsupported or out-of-range index")
         raise WgslError(f"internal: expression {tag}")
 
-    @staticmethod
-    def neg(k, v):
+    def neg(self, k, v):
         if k == "f32":
-            return k, -v
+            return k, self.low.neg(v)
         if k == "af":
             return k, -v
         if k == "ai":
@@ -930,7 +1014,7 @@ class Module:
         ka, kb = a.k, b.k
         k = _unify(ka, kb)
         if isinstance(a, Sc) and isinstance(b, Sc):
-            return Sc(*_scalar_binop(op, k, _convert(ka, a.v, k), _convert(kb, b.v, k)))
+            return Sc(*_scalar_binop(op, k, _convert(ka, a.v, k), _convert(kb, b.v, k), self.low))
         if op in ("==", "!=", "<", ">", "<=", ">=", "||", "&&"):
             raise WgslError("vector comparisons are outside the supported subset")
         n = len(a) if isinstance(a, Vec) else len(b)
@@ -938,7 +1022,7 @@ class Module:
         bc = b.c if isinstance(b, Vec) else (b.v,) * n
         if len(ac) != len(bc):
             raise WgslError("vector operands of different sizes")
-        out = [_scalar_binop(op, k, _convert(ka, x, k), _convert(kb, y, k)) for x, y in zip(ac, bc)]
+        out = [_scalar_binop(op, k, _convert(ka, x, k), _convert(kb, y, k), self.low) for x, y in zip(ac, bc)]
         return Vec(out[0][0], [o[1] for o in out])
 
     def construct(self, ty, args):
@@ -1084,7 +1168,7 @@ class Module:
                     raise WgslError("pow needs f32")
                 return F32(self.low.pow(x, y))
             if k == "f32":
-                return _fmax(x, y) if name == "max" else _fmin(x, y)
+                return F32(_fmax(x, y) if name == "max" else _fmin(x, y))      # (a plain f32: a product does not pass through)
             return max(x, y) if name == "max" else min(x, y)
 
         if isinstance(a, Sc) and isinstance(b, Sc):
