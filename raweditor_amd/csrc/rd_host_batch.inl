@@ -35,6 +35,8 @@ struct rd_batch {
         rd_frame_desc *dev = nullptr, *host = nullptr;
         size_t cap = 0, n = 0;
         hipEvent_t done = nullptr;             // after the last launch that reads the array
+        hipStream_t done_on = nullptr;         // ... and the stream that recorded it (another stream's call chains behind it, below)
+        bool done_set = false;
         hipEvent_t uploaded = nullptr;         // after the copy that filled it (a later call may come on another stream)
         bool valid = false;
     } db[2];
@@ -306,6 +308,9 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
         d.valid = true;
     }
     RD_HIP(hipStreamWaitEvent(s, b->db[j].uploaded, 0));         // (a reused array's copy may have been enqueued by a call on another stream)
+    // `done` is ONE event: re-recorded on this stream it would forget a reader still running on another stream, and the rewrite two
+    // calls on would wait for the wrong one.  A call that reuses an array from another stream therefore queues behind that reader.
+    if (b->db[j].done_set && b->db[j].done_on != s) RD_HIP(hipStreamWaitEvent(s, b->db[j].done, 0));
     b->db_last = j;
     const rd_frame_desc *descs = b->db[j].dev;
 
@@ -336,6 +341,8 @@ static int rd_batch_develop_multi(rd_batch *b, const rd_frame *frames, size_t n,
     }
     b->scratch.used(l, s, rc != RD_OK);
     RD_HIP(hipEventRecord(b->db[j].done, s));
+    b->db[j].done_on = s;
+    b->db[j].done_set = true;
     return rc;
 }
 
@@ -468,8 +475,8 @@ extern "C" int rd_batch_set_launch_timing(rd_batch *b, uint32_t keep_calls) try
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
     b->timeline.reserve((size_t)keep_calls * 64u + 64u);
-    b->ev_free.reserve((size_t)keep_calls * 128u + 128u);
-    for (auto &t : b->timeline) { b->ev_free.push_back(t.start); b->ev_free.push_back(t.end); }
+    b->ev_free.reserve(std::max((size_t)keep_calls * 128u + 128u, b->ev_free.size() + 2u * b->timeline.size()));   // (no growth, so no
+    for (auto &t : b->timeline)                                                                                   //  throw, in the loop below) { b->ev_free.push_back(t.start); b->ev_free.push_back(t.end); }
     b->timeline.clear();
     b->timing_keep = keep_calls;
     b->timing_call = 0;

@@ -254,6 +254,47 @@ def test_same_batch_on_two_streams_in_turn(gpu_lib, refc):
     be.close()
 
 
+def test_three_frame_arrays_rotating_over_two_unsynchronised_streams(gpu_lib, refc):
+    """Calls alternate between two streams WITHOUT a synchronise in between while three different frame arrays rotate: an
+    array is reused from the other stream (the call queues behind the array's previous reader) and rewritten two calls later
+    (after that reader has finished).  Every array has its own surfaces; all of them must hold the oracle's bits at the end."""
+    import ctypes as C
+    from raweditor_amd import _lib
+    from raweditor_amd._lib import check
+    ra = gpu_lib
+    h, w, n = 130, 640, 5
+    rng = np.random.default_rng([0x52415745, 2026])
+    cfas = [random_cfa(rng, h, w) for _ in range(n)]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    be = ra.BatchExporter(0, w, h, ra.FMT_RGBA_F32, False)
+    arrays, outs, exps = [], [], []
+    for a in range(3):
+        params = [ra.EditParams(**random_params(rng)) for _ in range(n)]
+        d_out = [DevBuf(h * w * 16) for _ in range(n)]
+        arrays.append(be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], params, WB_DAYLIGHT, CM_TEST))
+        outs.append(d_out)
+        exps.append([refc.render_f32(c, refc.make_uniforms({f: getattr(p, f) for f in ra.FIELDS}, WB_DAYLIGHT, CM_TEST))
+                     for c, p in zip(cfas, params)])
+    streams = []
+    for _ in range(2):
+        s = C.c_void_p()
+        check(_lib.lib().rd_stream_create(0, C.byref(s)))
+        streams.append(s.value)
+    order = [0, 0, 1, 2, 0, 1, 1, 2, 2, 0, 1, 2, 0, 0, 2, 1] * 3             # reuse from the other stream, rewrites, repeats
+    for k, a in enumerate(order):
+        be.develop(arrays[a], stream=streams[k % 2])
+    for s in streams:
+        check(_lib.lib().rd_stream_synchronize(0, C.c_void_p(s)))
+    for a in range(3):
+        for e, o in zip(exps[a], outs[a]):
+            assert np.array_equal(o.to_array(np.float32, (h, w, 4)).view(np.uint32), e.view(np.uint32)), a
+    for s in streams:
+        check(_lib.lib().rd_stream_destroy(0, C.c_void_p(s)))
+    be.close()
+    for b in d_in + [o for d in outs for o in d]:
+        b.free()
+
+
 # ------------------------------------------------------------------------------------------------
 # round 6: the measurement aids behind bench.py's self-diagnosis (rd_batch_set_launch_timing / _launch_timeline,
 # rd_batch_probe_pattern, rd_batch_measure_clock)
