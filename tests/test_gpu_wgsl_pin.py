@@ -38,6 +38,10 @@ def test_pipeline_reproduces_the_evaluated_shader(gpu_lib, refc, case, kernel):
     assert np.array_equal(got8, exp8)
     assert np.array_equal(got16.view(np.uint16), refc.pack_f16(exp).view(np.uint16))
     assert np.array_equal(hist, refc.histogram(exp8))
+    h, w = case["cfa"].shape
+    if (case["tw"], case["th"], case["zoom"], case["pan"]) == (w, h, 1.0, [0.0, 0.0]) and kernel == "auto":
+        # the reference's own export call (pipeline.rs:526-605)
+        assert np.array_equal(pipe.render_full_res_to_bytes().reshape(h, w, 4), exp8)
     pipe.close()
 
 
