@@ -140,10 +140,10 @@ def pixel_map(w, h, tw, th, zoom, pan_x, pan_y):
         sy = (j + F(0.5)) / F(th)
         tx = ((sx - F(0.5)) / F(zoom) - F(pan_x)) + F(0.5)
         ty = ((sy - F(0.5)) / F(zoom) - F(pan_y)) + F(0.5)
-        inx = (tx >= 0) & (tx <= 1)
-        iny = (ty >= 0) & (ty <= 1)
-        px = np.where(inx, tx * F(w), F(0)).astype(np.int32)
-        py = np.where(iny, ty * F(h), F(0)).astype(np.int32)
+        inx = ~((tx < 0) | (tx > 1))           # as the shader writes the test (:174-175): a NaN coordinate passes it ...
+        iny = ~((ty < 0) | (ty > 1))
+        px = np.where(inx & ~np.isnan(tx), tx * F(w), F(0)).astype(np.int32)      # ... and converts to 0 (i32 of a NaN)
+        py = np.where(iny & ~np.isnan(ty), ty * F(h), F(0)).astype(np.int32)
     # tx == 1.0 exactly -> px == w (one past the texture): kept as it is, the parity of shaders.rs:115-118 is taken on it;
     # every load clamps (demosaic)
     PX, PY = np.meshgrid(px, py)

@@ -247,12 +247,13 @@ void ref_pixel(const uint16_t *cfa, uint32_t w, uint32_t h, const ref_uniforms *
     float tx = ((sx - 0.5f) / u->zoom - u->pan_x) + 0.5f;
     float ty = ((sy - 0.5f) / u->zoom - u->pan_y) + 0.5f;
     rgba[3] = 1.0f;
-    if (!(tx >= 0.0f && tx <= 1.0f && ty >= 0.0f && ty <= 1.0f)) {
-        rgba[0] = rgba[1] = rgba[2] = 0.0f;  /* :174-178 */
+    if (tx < 0.0f || tx > 1.0f || ty < 0.0f || ty > 1.0f) {
+        rgba[0] = rgba[1] = rgba[2] = 0.0f;  /* :174-178 -- as written there: a NaN coordinate (zoom = 0) passes all four tests */
         return;
     }
-    int32_t px = (int32_t)(tx * (float)w);
-    int32_t py = (int32_t)(ty * (float)h);
+    /* :184-187 i32(f32): truncation; of a NaN it is implementation-defined -- 0 here, what GPUs' conversions return */
+    int32_t px = tx != tx ? 0 : (int32_t)(tx * (float)w);
+    int32_t py = ty != ty ? 0 : (int32_t)(ty * (float)h);
     /* tx == 1.0 exactly gives px == w, one past the texture, and the shader carries that coordinate on (:184-192): the Bayer
      * parity is taken on it as it is; only the loads see a border -- get_neighbor clamps (:164-167) and the centre load of
      * :106 is out of bounds, which this repository lowers as a clamp too (tap()).  Pinned by the evaluated shader text:

@@ -16,6 +16,7 @@ What the WGSL specification leaves to the implementation is NOT decided in here;
     dot / matrix * vector            (summation order)
     mix(x, y, a)                     (x * (1 - a) + y * a  or  x + (y - x) * a; the specification allows both)
     min / max / clamp on NaN         (implementation-defined)
+    division                         (2.5 ulp are granted: the correctly rounded quotient, or x * (1 / y))
     f32 -> i32 of NaN, textureLoad out of bounds
 Everything else follows the specification: literals without a suffix are AbstractInt / AbstractFloat (64-bit), constant
 sub-expressions are evaluated in that type and converted once when they meet a concrete operand, there are no implicit
@@ -233,10 +234,13 @@ class Lowering:
     minus, whatever the number of uses (the aggressive form).  dot and mix are built from the same mul / add / sub."""
 
     def __init__(self, pow, dot_order="left_to_right", mix_form="x*(1-a)+y*a", nan_minmax="other_operand",
-                 nan_to_int=0, texture_oob="clamp", contraction="none"):
+                 nan_to_int=0, texture_oob="clamp", contraction="none", division="ieee"):
         if contraction not in ("none", "fuse"):
             raise WgslError("unknown contraction rule")
+        if division not in ("ieee", "reciprocal"):
+            raise WgslError("unknown division rule")
         self.fuse = contraction == "fuse"
+        self.reciprocal = division == "reciprocal"
         if dot_order != "left_to_right":
             raise WgslError("only left-to-right dot products are implemented")
         if mix_form not in ("x*(1-a)+y*a", "x+(y-x)*a"):
@@ -271,6 +275,14 @@ class Lowering:
                 return fma_f32(-b.factors[0], b.factors[1], a)
         with np.errstate(all="ignore"):
             return F32(a) - F32(b)
+
+    def div(self, a, b):
+        """division = "ieee": the correctly rounded quotient.  "reciprocal": x * round(1 / y), two roundings -- inside the 2.5 ulp
+        the specification grants f32 division, and what a compiler does that turns a division into a multiplication."""
+        with np.errstate(all="ignore"):
+            if self.reciprocal:
+                return self.mul(F32(a), F32(1.0) / F32(b))
+            return F32(a) / F32(b)
 
     def neg(self, a):
         if self.fuse and isinstance(a, Product):
@@ -609,8 +621,8 @@ def _scalar_binop(op, k, a, b, low=None):
             return "bool", a or b
         raise WgslError(f"operator {op} on bool")
     if k == "f32":
-        if low is not None and op in ("+", "-", "*"):
-            return k, {"+": low.add, "-": low.sub, "*": low.mul}[op](a, b)
+        if low is not None and op in ("+", "-", "*", "/"):
+            return k, {"+": low.add, "-": low.sub, "*": low.mul, "/": low.div}[op](a, b)
         with np.errstate(all="ignore"):
             if op == "+":
                 return k, a + b

@@ -16,6 +16,8 @@ The two differ by an ulp here and there in tex_coords and therefore only where a
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 from . import wgsl_eval as we
@@ -95,8 +97,12 @@ def check_vertex_stage(verts, zoom, pan_x, pan_y, tol=4e-7):
         if clip != (x, -y):
             raise we.WgslError(f"vertex position {clip} is not ({x}, {-y})")
         for got, ndc, pan in ((tex[0], x, pan_x), (tex[1], y, pan_y)):
-            want = ((ndc + 1.0) * 0.5 - 0.5) / float(F32(zoom)) - float(F32(pan)) + 0.5
-            if abs(got - want) > tol * max(1.0, abs(want)):
+            with np.errstate(all="ignore"):                      # zoom = 0: the quotient is an infinity (or a NaN), also in vs_main
+                want = float(np.float64((ndc + 1.0) * 0.5 - 0.5) / np.float64(F32(zoom)) - np.float64(F32(pan)) + 0.5)
+            if math.isnan(want) or math.isinf(want):
+                if not (math.isnan(got) and math.isnan(want)) and got != want:
+                    raise we.WgslError(f"vertex tex coordinate {got} differs from the affine model's {want}")
+            elif not abs(got - want) <= tol * max(1.0, abs(want)):
                 raise we.WgslError(f"vertex tex coordinate {got} differs from the affine model's {want}")
 
 

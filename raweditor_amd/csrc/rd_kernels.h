@@ -1732,9 +1732,9 @@ rd_develop_map(const uint16_t *__restrict__ cfa, void *__restrict__ out, uint32_
         const float tx = ((sx - 0.5f) / u.zoom - u.pan_x) + 0.5f;
         const float ty = ((sy - 0.5f) / u.zoom - u.pan_y) + 0.5f;
         rd_rgb c = { 0.0f, 0.0f, 0.0f };
-        if (tx >= 0.0f && tx <= 1.0f && ty >= 0.0f && ty <= 1.0f) {
-            int32_t px = (int32_t)(tx * (float)W);
-            int32_t py = (int32_t)(ty * (float)H);
+        if (!(tx < 0.0f || tx > 1.0f || ty < 0.0f || ty > 1.0f)) {   // the shader's own test (:174-175): a NaN coordinate (zoom = 0) passes it
+            int32_t px = tx != tx ? 0 : (int32_t)(tx * (float)W);    // ... and i32(NaN) is 0 (the pinned lowering; what v_cvt_i32_f32 returns)
+            int32_t py = ty != ty ? 0 : (int32_t)(ty * (float)H);
             // tx == 1.0 exactly: px == W, one past the frame.  The shader carries that coordinate on -- the Bayer parity is taken on
             // it -- and only its loads see the border (rd_tap clamps every one, the centre's included).
             c = rd_develop_px<MATH, Q8ONLY>(cfa, W, H, px, py, u);   // Q8ONLY: linear values; rd_q8_gamma finishes (out-of-bounds pixels stay 0 -> code 0)

@@ -204,7 +204,9 @@ def main():
         if rng.random() < 0.5:
             view = (int(rng.integers(1, 300)), int(rng.integers(1, 200)), float(F(rng.choice((1.0, rng.uniform(0.3, 8.0))))),
                     float(F(rng.uniform(-0.7, 0.7))), float(F(rng.uniform(-0.7, 0.7))))
-            if rng.random() < 0.1:                                   # tex_coords of exactly 0.0 and 1.0: zoom 1/2, an even target, no pan
+            if rng.random() < 0.03:                                  # zoom = 0: infinite coordinates, NaN at the centre of an odd target
+                view = (2 * int(rng.integers(0, 40)) + 1, 2 * int(rng.integers(0, 30)) + 1, 0.0, float(rng.choice((0.0, 0.25))), 0.0)
+            elif rng.random() < 0.1:                                 # tex_coords of exactly 0.0 and 1.0: zoom 1/2, an even target, no pan
                 view = (2 * int(rng.integers(1, 150)), 2 * int(rng.integers(1, 100)), 0.5, 0.0, 0.0)   # (pixel_coords = W: parity on W)
             views += 1
         bad, flags = check(case, view)

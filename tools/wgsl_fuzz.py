@@ -79,6 +79,8 @@ def draw_view(rng, h, w):
         return tw, th, 1.0, (0.0, 0.0)
     if r < 0.6:                                          # tex_coords hit 0.0 and 1.0 exactly: zoom 1/2, even target
         return 2 * int(rng.integers(1, 4)), 2 * int(rng.integers(1, 3)), 0.5, (0.0, 0.0)
+    if r < 0.64:                                         # zoom = 0: infinite coordinates (black) and, at the centre of an odd target, NaN
+        return 2 * int(rng.integers(0, 4)) + 1, 2 * int(rng.integers(0, 3)) + 1, 0.0, (f32(rng.choice([0.0, 0.25])), 0.0)
     zoom = f32(rng.choice([0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0, 8.0]) if rng.random() < 0.5 else rng.uniform(0.2, 6.0))
     pan = (f32(rng.uniform(-0.6, 0.6)), f32(rng.uniform(-0.6, 0.6))) if rng.random() < 0.7 else (0.5, -0.5)
     return tw, th, zoom, pan

@@ -3,7 +3,7 @@
 
 Evaluates the shader string of /root/reference/src/gpu/shaders.rs (oracle/wgsl_eval.py) on the inputs of
 tests/golden/wgsl_golden.npz under the lowering this repository pinned and under alternatives a driver could pick (pow as a
-binary64 pow rounded once; mix as x + (y - x) a; both; multiplications fused into the additions that consume them the way an
+binary64 pow rounded once; mix as x + (y - x) a; both; division as a multiplication by the reciprocal; multiplications fused into the additions that consume them the way an
 LLVM-style compiler orders it), packs each result to RGBA8 with the pinned UNORM rule and reports, against
 the pinned lowering: the share of colour bytes that differ, the largest difference in codes, and the largest f32 difference in
 units of the last place.  It measures the room DESIGN.md section 2 talks about on the text itself, not on a restatement.
@@ -30,6 +30,8 @@ ALTERNATIVES = {
     "contraction (LLVM operand order)": lambda: we.Lowering(pow=pow_pinned_scalar, contraction="fuse"),
     "contraction + mix x + (y - x) a": lambda: we.Lowering(pow=pow_pinned_scalar, contraction="fuse", mix_form="x+(y-x)*a"),
     "contraction + both": lambda: we.Lowering(pow=we.pow_f64_rounded, contraction="fuse", mix_form="x+(y-x)*a"),
+    "division = x * (1 / y)": lambda: we.Lowering(pow=pow_pinned_scalar, division="reciprocal"),
+    "all four": lambda: we.Lowering(pow=we.pow_f64_rounded, contraction="fuse", mix_form="x+(y-x)*a", division="reciprocal"),
 }
 
 
@@ -43,7 +45,7 @@ def larger_sample(src, frames):
         cfa = random_cfa(rng, 16, 24)
         params = mild_params(rng) if n % 4 else random_params(rng)
         block = wr.uniform_block(params, WB_DAYLIGHT, CM_TEST)
-        alt = wr.render(src, cfa, block, lowering=ALTERNATIVES["contraction + both"]())["rgba"]
+        alt = wr.render(src, cfa, block, lowering=ALTERNATIVES["all four"]())["rgba"]
         pinned = ref_c.render_f32(cfa, ref_c.make_uniforms(params, WB_DAYLIGHT, CM_TEST))
         d = np.abs(ref_c.pack_u8(alt)[..., :3].astype(np.int32) - ref_c.pack_u8(pinned)[..., :3].astype(np.int32))
         total += d.size
@@ -53,7 +55,7 @@ def larger_sample(src, frames):
         worst = max(worst, int(d.max()))
         if (n + 1) % 50 == 0:
             print(f"# {n + 1} frames, {total} colour bytes, {differing} differ", flush=True)
-    print(f"larger sample, contraction + both against the pinned lowering: {frames} frames of 16 x 24, {total} colour bytes, "
+    print(f"larger sample, all four (pow, mix, contraction, division) against the pinned lowering: {frames} frames of 16 x 24, {total} colour bytes, "
           f"{differing} differ ({100.0 * differing / total:.4f} %), by codes: {dict(sorted(hist.items()))}, largest {worst}")
 
 
