@@ -99,6 +99,8 @@ def check_vertex_stage(verts, zoom, pan_x, pan_y, tol=4e-7):
         for got, ndc, pan in ((tex[0], x, pan_x), (tex[1], y, pan_y)):
             with np.errstate(all="ignore"):                      # zoom = 0: the quotient is an infinity (or a NaN), also in vs_main
                 want = float(np.float64((ndc + 1.0) * 0.5 - 0.5) / np.float64(F32(zoom)) - np.float64(F32(pan)) + 0.5)
+            if abs(want) > 3.4028235677973366e38:                # beyond f32: the shader's own quotient has overflowed
+                want = math.copysign(math.inf, want)
             if math.isnan(want) or math.isinf(want):
                 if not (math.isnan(got) and math.isnan(want)) and got != want:
                     raise we.WgslError(f"vertex tex coordinate {got} differs from the affine model's {want}")
