@@ -141,3 +141,47 @@ def render(source, cfa, uniforms, tw=None, th=None, lowering=None, raster="pixel
             rgba = mod.call(fragment_fn, frag)
             out[j, i] = rgba.c
     return dict(rgba=out, tex=tc, oob_loads=tex.oob_loads, nan_to_int=mod.nan_to_int)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# whole frames: the same draw through the many-fragments-at-a-time evaluator (oracle/wgsl_vec.py)
+# ---------------------------------------------------------------------------------------------------------------------------
+def render_rows(source, cfa, uniforms, lowering, row0, row1, tw=None, th=None, fragment_fn="fs_main", module=None):
+    """Rows [row0, row1) of the tw x th target as ((row1 - row0), tw, 4) float32, rasteriser model "pixel_centre_f32", all
+    fragments of the band evaluated at once.  `lowering.pow` must map an array and one exponent to an array.  Pass the
+    returned module back in (`module=`) to reuse the parsed shader and its bindings for the next band.
+    -> (rgba, module)"""
+    from . import wgsl_vec as wv
+    h, w = np.asarray(cfa).shape
+    tw, th = (w if tw is None else int(tw)), (h if th is None else int(th))
+    if module is None:
+        module = wv.VectorModule(source, lowering)
+        module.texture = we.Texture2D(np.asarray(cfa, np.uint16))
+        module.bind("input_texture", module.texture)
+        module.bind("params", uniforms)
+        check_vertex_stage(run_vertex_stage(module), uniforms["zoom"], uniforms["pan_x"], uniforms["pan_y"])
+    zoom, pan_x, pan_y = F32(uniforms["zoom"]), F32(uniforms["pan_x"]), F32(uniforms["pan_y"])
+    sx = (np.arange(tw, dtype=F32) + F32(0.5)) / F32(tw)
+    sy = (np.arange(row0, row1, dtype=F32) + F32(0.5)) / F32(th)
+    with np.errstate(all="ignore"):
+        tx = ((sx - F32(0.5)) / zoom - pan_x) + F32(0.5)
+        ty = ((sy - F32(0.5)) / zoom - pan_y) + F32(0.5)
+    n = (row1 - row0) * tw
+    txs = np.ascontiguousarray(np.broadcast_to(tx[None, :], (row1 - row0, tw))).reshape(n)
+    tys = np.ascontiguousarray(np.broadcast_to(ty[:, None], (row1 - row0, tw))).reshape(n)
+    varying = module.fns[fragment_fn][0][0][1].name
+    zero = np.zeros(n, F32)
+    frag = module.make_struct(varying, dict(clip_position=[zero, zero, zero, zero], tex_coords=[txs, tys]))
+    out = module.call(fragment_fn, frag)
+    rgba = np.empty((n, 4), F32)
+    for k, comp in enumerate(out.c):
+        rgba[:, k] = comp
+    return rgba.reshape(row1 - row0, tw, 4), module
+
+
+def pow_pinned_lanes(x, y):
+    """The pinned pow pair (oracle/develop_np.py: pow_pinned) for one value or an array of them, one exponent."""
+    from . import develop_np as dn
+    if np.ndim(x) == 0:
+        return dn.pow_pinned(np.array([x], F32), y)[0]
+    return dn.pow_pinned(np.asarray(x, F32), y)

@@ -94,3 +94,75 @@ def test_batch_entry_reproduces_the_evaluated_shader(gpu_lib, refc, shape, group
         be.close()
         for b in d_in + d_out + [d_hist]:
             b.free()
+
+
+# ---- whole frames: BASELINE's sizes against the checksums of the evaluated shader text ----------------------------------------
+from tests.test_wgsl_pin_cpu import FULL, fullsize_check, fullsize_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("fr", FULL["frames"], ids=[f["name"] for f in FULL["frames"]])
+def test_pipeline_reproduces_the_evaluated_shader_at_full_size(gpu_lib, fr):
+    """24 MP (aligned, ragged and odd width) and 100 MP frames through the RenderPipeline mirror: the f32 surface (band CRCs, then
+    SHA-256), the fused histogram, the RGBA8 bytes of render_full_res_to_bytes and the binary16 surface against
+    tests/golden/wgsl_fullsize.json -- checksums of what the reference's shader text evaluates to (tools/make_wgsl_fullsize.py)."""
+    ra = gpu_lib
+    cfa = fullsize_inputs(fr)
+    pipe = make_pipe(ra, cfa, fr["params"], FULL["wb"], fr["cm"])
+    got, hist = pipe.render(fmt=ra.FMT_RGBA_F32, with_histogram=True)
+    fullsize_check(fr, f32=got, hist=hist)
+    del got
+    fullsize_check(fr, rgba8=pipe.render_full_res_to_bytes().reshape(fr["h"], fr["w"], 4))
+    f16, hist16 = pipe.render(fmt=ra.FMT_RGBA_F16, with_histogram=True)
+    fullsize_check(fr, f16=f16, hist=hist16)
+    pipe.close()
+
+
+def _full_groups():
+    by = {}
+    for fr in FULL["frames"]:
+        by.setdefault((fr["w"], fr["h"]), []).append(fr)
+    return sorted(by.items())
+
+
+@pytest.mark.parametrize("size,group", _full_groups(), ids=[f"{s[0]}x{s[1]}" for s, _ in _full_groups()])
+@pytest.mark.parametrize("bands", [1, 8])
+def test_batch_entry_reproduces_the_evaluated_shader_at_full_size(gpu_lib, size, group, bands):
+    """The batch entry on the same frames: the frames of one size in one call -- multi-frame launches (bands = 1, the default)
+    and BASELINE config 5's wording, eight row-band launches per frame -- f32 for the 24 MP sizes, binary16 for the 100 MP
+    frame (config 5's surface), RGBA8 and RGB8 for all, with the accumulated histogram."""
+    ra = gpu_lib
+    w, h = size
+    cfas = [fullsize_inputs(fr) for fr in group]
+    d_in = [DevBuf.from_array(c) for c in cfas]
+    want_hist = sum(np.asarray(fr["histogram"], np.uint64) for fr in group)
+    wide = ra.FMT_RGBA_F16 if w * h > 30_000_000 else ra.FMT_RGBA_F32
+    for fmt in (wide, ra.FMT_RGBA_U8, ra.FMT_RGB_U8):
+        bpp = ra.BYTES_PER_PIXEL[fmt]
+        d_out = [DevBuf(h * w * bpp) for _ in group]
+        d_hist = DevBuf(768 * 8)
+        be = ra.BatchExporter(0, w, h, fmt, True)
+        frames = be.make_frames([b.ptr for b in d_in], [b.ptr for b in d_out], [ra.EditParams(**fr["params"]) for fr in group],
+                                FULL["wb"], group[0]["cm"])
+        for f, fr in zip(frames, group):
+            f.color_matrix[:] = fr["cm"]
+        be.develop(frames, row_bands=bands)
+        be.histogram(d_hist.ptr)
+        sync()
+        for fr, o in zip(group, d_out):
+            if fmt == ra.FMT_RGBA_F32:
+                fullsize_check(fr, f32=o.to_array(np.float32, (h, w, 4)))
+            elif fmt == ra.FMT_RGBA_F16:
+                fullsize_check(fr, f16=o.to_array(np.uint16, (h, w, 4)))
+            elif fmt == ra.FMT_RGBA_U8:
+                fullsize_check(fr, rgba8=o.to_array(np.uint8, (h, w, 4)))
+            else:                                                    # RGB8 = the RGBA8 bytes without their alpha
+                rgb = o.to_array(np.uint8, (h, w, 3))
+                rgba = np.full((h, w, 4), 255, np.uint8)
+                rgba[..., :3] = rgb
+                fullsize_check(fr, rgba8=rgba)
+        assert np.array_equal(d_hist.to_array(np.uint64, (768,)), want_hist), (size, fmt)
+        be.close()
+        for b in d_out + [d_hist]:
+            b.free()
+    for b in d_in:
+        b.free()
