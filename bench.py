@@ -1210,9 +1210,67 @@ def extra_ragged_width(torch, np, ra, dev, dev_index, cfas, params, stream, valu
     return out
 
 
+def extra_text_pin(torch, np, ra, dev, dev_index, stream):
+    """The batch path against the reference's SHADER TEXT, executed: tests/golden/wgsl_fullsize.json holds checksums of whole frames
+    evaluated from /root/reference/src/gpu/shaders.rs by this repository's WGSL evaluator (tools/make_wgsl_fullsize.py, made in
+    the build container; only the checksums travel).  The frames' inputs are re-drawn from their seeded PCG64 streams (checked
+    against their own hash), developed by ONE rd_batch_develop call per size -- f32 surface for the 24 MP frames (aligned, ragged,
+    odd width), binary16 for the 100 MP frame -- and the surfaces' SHA-256 and the accumulated histogram compared.  No oracle
+    code runs here: hashes of what the device wrote against hashes in a data file."""
+    import hashlib
+    import zlib
+    with open(os.path.join(ROOT, "tests", "golden", "wgsl_fullsize.json")) as fh:
+        full = json.load(fh)
+    groups = {}
+    for fr in full["frames"]:
+        groups.setdefault((fr["w"], fr["h"]), []).append(fr)
+    out = {"source": "tests/golden/wgsl_fullsize.json (shader sha256 " + full["shader_sha256"][:16] + "...)", "frames": {}}
+    results, skipped = [], False
+    for (w, h), group in sorted(groups.items()):
+        wide = w * h > 30_000_000
+        fmt, key, dt = (ra.FMT_RGBA_F16, "sha256_f16", torch.uint8) if wide else (ra.FMT_RGBA_F32, "sha256_f32", torch.uint8)
+        planes = []
+        for fr in group:
+            rng = np.random.default_rng([full["seed"], zlib.crc32(fr["name"].encode())])
+            cfa = rng.integers(0, 4096, (h, w), dtype=np.uint16)
+            if hashlib.sha256(cfa.tobytes()).hexdigest() != fr["sha256_cfa"]:
+                out["frames"][fr["name"]] = "inputs differ (this numpy draws another plane): not compared"
+                skipped, planes = True, None
+                break
+            planes.append(torch.from_numpy(cfa.view(np.int16)).to(dev))
+        if planes is None:
+            continue
+        bpp = ra.BYTES_PER_PIXEL[fmt]
+        outs = [torch.empty(h * w * bpp, dtype=dt, device=dev) for _ in group]
+        hist = torch.zeros(768, dtype=torch.int64, device=dev)
+        be = ra.BatchExporter(dev_index, w, h, fmt, True)
+        frames = be.make_frames([c.data_ptr() for c in planes], [o.data_ptr() for o in outs], [ra.EditParams(**fr["params"]) for fr in group],
+                                full["wb"], group[0]["cm"])
+        for f, fr in zip(frames, group):
+            f.color_matrix[:] = fr["cm"]
+        with torch.cuda.stream(stream):
+            be.develop(frames, stream=stream.cuda_stream)
+            be.histogram(hist.data_ptr(), stream=stream.cuda_stream)
+            stream.synchronize()
+        want_hist = np.sum([np.asarray(fr["histogram"], np.int64) for fr in group], axis=0)
+        hist_ok = bool(np.array_equal(hist.cpu().numpy(), want_hist))
+        for fr, o in zip(group, outs):
+            ok = hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest() == fr[key]
+            out["frames"][fr["name"]] = {"surface": "f16" if wide else "f32", "sha256_matches": bool(ok), "histogram_matches": hist_ok}
+            results.append(bool(ok) and hist_ok)
+        be.close()
+        del planes, outs
+    out["verified"] = (all(results) if results and not skipped else (False if results and not all(results) else None))
+    return out
+
+
 def extra_configs(torch, np, ra, dev, dev_index, cfas, params, stream, valu_ns=None):
     out = {}
     t0 = time.perf_counter()
+    try:
+        out["text_pin"] = extra_text_pin(torch, np, ra, dev, dev_index, stream)
+    except Exception as e:  # noqa: BLE001  (a data file or numpy difference must not cost the other extras)
+        out["text_pin"] = {"verified": None, "error": f"{type(e).__name__}: {e}"}
     out["single_frame_f32"] = extra_single_frame(torch, np, ra, dev, dev_index, cfas[0], params[0], stream)
     out["full_res_to_bytes"] = extra_full_res_to_bytes(torch, np, ra, dev, dev_index, cfas[1], params[1])
     out["export_ring"] = extra_export_ring(torch, np, ra, dev, dev_index, cfas[:8], params[:8])
@@ -1595,6 +1653,8 @@ def run_ranks(args):
                 "odd_width_ns_per_px_ratio": {k: ((ex.get("odd_width") or {}).get(k) or {}).get("ns_per_px_ratio") for k in ("f32", "f16", "u8", "rgb8")},
                 "all_verified": all(bool((ex.get(k) or {}).get("verified")) for k in ("single_frame_f32", "full_res_to_bytes", "batch_rgba8", "config5_shape_f16",
                                                                                    "config5_shape_f16_tiled", "ragged_width", "odd_width")) if ex and "error" not in ex else None,
+                # whole frames against checksums of the reference's shader text, evaluated (tests/golden/wgsl_fullsize.json)
+                "text_pin_verified": (ex.get("text_pin") or {}).get("verified"),
             },
             "verified": result.get("verified"),
             "cpu_baseline_MPps": (result.get("cpu_baseline") or {}).get("value"),

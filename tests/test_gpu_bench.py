@@ -116,6 +116,12 @@ def test_single_gpu_line_carries_the_other_configs(gpu_lib):
     assert ow["verified"] is True and "6001x4001" in ow["config"] and "ODD" in ow["config"]
     for k in ("f32", "f16", "u8", "rgb8"):
         assert ow[k]["verified"] is True and 0.8 < ow[k]["ns_per_px_ratio"] < 1.6, (k, ow[k])
+    # round 6: whole frames of the batch path against checksums of the reference's shader text, evaluated (no oracle involved)
+    tp = ex["text_pin"]
+    assert tp["verified"] is True and len(tp["frames"]) == 7, tp
+    assert all(v["sha256_matches"] and v["histogram_matches"] for v in tp["frames"].values())
+    assert tp["frames"]["full_11648x8736_mild"]["surface"] == "f16" and tp["frames"]["full_6001x4001_mild"]["surface"] == "f32"
+    assert r["diagnosis"]["extras"]["text_pin_verified"] is True
     # the f32 kernel's issue budget (round 5: scalar-base store addresses; parking the slider uniforms measured negative and is off),
     # and the bound as this run's fractions say it
     assert r["roofline"]["valu_issue_cycles_per_tile"] == 1360 and r["roofline"]["bound"] == "hbm"

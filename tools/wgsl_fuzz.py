@@ -86,12 +86,50 @@ def draw_view(rng, h, w):
     return tw, th, zoom, pan
 
 
+def vector_run(src, frames, seed):
+    """Larger frames (up to 96 x 128, views up to 160 x 120) through the array-at-a-time evaluator (oracle/wgsl_vec.py), pinned pow
+    flavour only (numpy's binary64 power is not the C library's, so the other flavour stays with the scalar evaluator)."""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    px = oob = nans = interior = 0
+    for n in range(frames):
+        h, w = int(rng.integers(1, 97)), int(rng.integers(1, 129))
+        cfa = draw_frame(rng)
+        cfa = np.resize(cfa, (h, w)) if rng.random() < 0.2 else rng.integers(0, int(rng.choice([64, 4096, 65536])), (h, w)).astype(np.uint16)
+        tw, th, zoom, pan = draw_view(rng, h, w)
+        if (tw, th) != (w, h) and rng.random() < 0.5:
+            tw, th = int(rng.integers(1, 161)), int(rng.integers(1, 121))
+        params = draw_params(rng)
+        wb = [f32(x) for x in rng.uniform(0.5, 3.0, 4)]
+        cm = [f32(x) for x in (rng.uniform(-1.0, 2.0, 9) if rng.random() < 0.7 else np.eye(3).reshape(-1))]
+        block = wr.uniform_block(params, wb, cm, zoom, pan[0], pan[1])
+        got, mod = wr.render_rows(src, cfa, block, we.Lowering(pow=wr.pow_pinned_lanes), 0, th, tw, th)
+        o = ref_c.render_f32(cfa, ref_c.make_uniforms(params, wb, cm, zoom, pan[0], pan[1]), tw, th)
+        if not np.array_equal(o.view(np.uint32), got.view(np.uint32)):
+            bad = np.argwhere((o.view(np.uint32) != got.view(np.uint32)).any(axis=2))
+            print(f"MISMATCH frame {n}: {len(bad)} pixel(s), first at (row, col) = {tuple(bad[0])}; frame {w}x{h}, target {tw}x{th}, zoom {zoom}, "
+                  f"pan {pan}\n  params {params}\n  wb {wb} cm {cm}\n  oracle {o[tuple(bad[0])].tolist()} evaluated {got[tuple(bad[0])].tolist()}")
+            raise SystemExit(1)
+        px += tw * th
+        oob += mod.texture.oob_loads
+        nans += mod.nan_to_int
+        interior += int(((got[..., :3] > 0) & (got[..., :3] < 1)).any(axis=2).sum())
+        if (n + 1) % 2000 == 0:
+            print(f"# {n + 1} frames, {px} pixels, {time.time() - t0:.0f} s", flush=True)
+    print(f"wgsl_fuzz --vector: seed {seed:#x}: {frames} frames, {px} output pixels, evaluated shader text (array-at-a-time evaluator, pinned pow) == "
+          f"C oracle bit for bit on all of them; {oob} out-of-bounds centre loads, {nans} NaN coordinates converted, {interior} pixels with a "
+          f"channel strictly inside (0, 1); {time.time() - t0:.0f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=0x57475346)
+    ap.add_argument("--vector", action="store_true", help="larger frames through oracle/wgsl_vec.py (pinned pow only)")
     a = ap.parse_args()
     src = shader_source()
+    if a.vector:
+        return vector_run(src, a.frames, a.seed)
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     px = oob = nan_px = border_px = interior = 0
