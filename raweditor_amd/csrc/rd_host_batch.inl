@@ -475,8 +475,9 @@ extern "C" int rd_batch_set_launch_timing(rd_batch *b, uint32_t keep_calls) try
     rd_devguard g(b->device);
     if (!g.ok) return rd_fail(RD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", b->device);
     b->timeline.reserve((size_t)keep_calls * 64u + 64u);
-    b->ev_free.reserve(std::max((size_t)keep_calls * 128u + 128u, b->ev_free.size() + 2u * b->timeline.size()));   // (no growth, so no
-    for (auto &t : b->timeline)                                                                                   //  throw, in the loop below) { b->ev_free.push_back(t.start); b->ev_free.push_back(t.end); }
+    // (room for every event before the loop: no growth, so nothing can throw between an event's two homes)
+    b->ev_free.reserve(std::max((size_t)keep_calls * 128u + 128u, b->ev_free.size() + 2u * b->timeline.size()));
+    for (auto &t : b->timeline) { b->ev_free.push_back(t.start); b->ev_free.push_back(t.end); }
     b->timeline.clear();
     b->timing_keep = keep_calls;
     b->timing_call = 0;
