@@ -65,6 +65,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             other.append(line); in_remark = False
     if other:
         print("\n".join(other), file=sys.stderr)
+    nwarn = sum(": warning:" in line for line in other)
+    if nwarn:                                                    # last thing on stderr, so that a glance at the tail of a build log sees it
+        print(f"raweditor_amd.build: {nwarn} compiler warning line(s) above -- the tree is kept clean under -Wall -Wextra", file=sys.stderr)
     if out.returncode != 0:
         raise subprocess.CalledProcessError(out.returncode, cmd)
     res = parse_resource_remarks(remarks)
